@@ -1,0 +1,13 @@
+"""Import shim: the package directory is ``i-vit_amd/`` (not a valid Python
+identifier), so ``import ivit_amd`` loads it under this name."""
+import importlib.util
+import os
+import sys
+
+_pkg_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "i-vit_amd")
+_spec = importlib.util.spec_from_file_location(
+    "ivit_amd", os.path.join(_pkg_dir, "__init__.py"),
+    submodule_search_locations=[_pkg_dir])
+_mod = importlib.util.module_from_spec(_spec)
+sys.modules["ivit_amd"] = _mod
+_spec.loader.exec_module(_mod)

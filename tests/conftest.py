@@ -1,0 +1,35 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def golden_scales(g):
+    return {k[len("scale/"):]: np.float32(g[k]) for k in g.files if k.startswith("scale/")}
+
+
+def csum(a):
+    """same checksum as tools/make_golden.py"""
+    a = np.asarray(a).astype(np.int64).reshape(-1)
+    idx = np.arange(1, a.size + 1, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        return np.uint64(((a.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)) ^ idx).sum())
+
+
+@pytest.fixture(scope="session")
+def ops_golden():
+    return load_golden("ops.npz")

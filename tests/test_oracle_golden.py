@@ -1,0 +1,114 @@
+"""Pins the CPU oracle (oracle/) against golden vectors produced by the reference
+itself (tools/make_golden.py).  CPU only."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, golden_scales, csum
+import ivit_amd as iv
+from oracle import oracle as orc
+
+
+def _digest(w):
+    h = hashlib.sha256()
+    for k in sorted(w):
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(w[k]).tobytes())
+    return h.hexdigest()
+
+
+def test_torch_sum_order(ops_golden):
+    g = ops_golden
+    for i in range(int(g["sum/n"])):
+        x = g[f"sum/{i}/x"]
+        got = np.array([orc.torch_sum(r) for r in x], np.float32)
+        assert np.array_equal(got, g[f"sum/{i}/out"]), f"C={x.shape[1]}"
+
+
+def test_quantize_input(ops_golden):
+    g = ops_golden
+    q = orc.quantize_f32(g["quant_in/x"], float(g["quant_in/s"]), 8)
+    assert np.array_equal(q, g["quant_in/out"].astype(np.int32))
+
+
+def test_shiftmax(ops_golden):
+    g = ops_golden
+    for i in range(int(g["shiftmax/n"])):
+        out = orc.shiftmax(g[f"shiftmax/{i}/x"], float(g[f"shiftmax/{i}/s"]), int(g[f"shiftmax/{i}/bits"]))
+        assert np.array_equal(out, g[f"shiftmax/{i}/out"]), i
+
+
+def test_shiftgelu(ops_golden):
+    g = ops_golden
+    for i in range(int(g["gelu/n"])):
+        out = orc.shiftgelu(g[f"gelu/{i}/x"], float(g[f"gelu/{i}/s"]))
+        assert np.array_equal(out, g[f"gelu/{i}/out"]), i
+
+
+def test_layernorm_and_perchannel_requant(ops_golden):
+    g = ops_golden
+    for i in range(int(g["ln/n"])):
+        x = g[f"ln/{i}/x"]
+        bias_int, sc = orc.layernorm_consts(g[f"ln/{i}/w"], g[f"ln/{i}/b"], x.shape[1])
+        z = orc.layernorm(x, float(g[f"ln/{i}/s"]), bias_int, sc)
+        assert np.array_equal(z, g[f"ln/{i}/z"]), i
+        out8 = orc.requant(z, orc.dyadic(sc, g[f"ln/{i}/s_out"]), 8)
+        assert np.array_equal(out8, g[f"ln/{i}/out8"].astype(np.int32)), i
+
+
+def test_requant(ops_golden):
+    g = ops_golden
+    for i in range(int(g["requant/n"])):
+        z = g[f"requant/{i}/z"]
+        s_out = g[f"requant/{i}/s_out"]
+        bits = int(g[f"requant/{i}/bits"])
+        dy = orc.dyadic(g[f"requant/{i}/s_pre"], s_out)
+        if f"requant/{i}/z_id" in g.files:
+            zi = g[f"requant/{i}/z_id"].astype(np.float32)
+            out = orc.requant(z, dy, bits, zi, orc.dyadic(g[f"requant/{i}/s_id"], s_out))
+        else:
+            out = orc.requant(z, dy, bits)
+        assert np.array_equal(out, g[f"requant/{i}/out"]), i
+
+
+@pytest.mark.parametrize("fname", ["micro_vit_b2.npz", "micro_vit2h_b3.npz"])
+def test_micro_model_every_site(fname):
+    g = load_golden(fname)
+    cfg = iv.CONFIGS[str(g["cfg_name"])]
+    w = iv.make_vit_weights(cfg, int(g["seed"]))
+    assert _digest(w) == str(g["weights_sha256"])
+    o = orc.OracleViT(cfg, w, golden_scales(g))
+    cap = {}
+    logits, s_head = o.forward(iv.make_images_int8(cfg, int(g["batch"]), int(g["images_seed"])), cap)
+    for n in g["sites"]:
+        n = str(n)
+        ref = g["site/" + n]
+        got = np.asarray(cap[n]).reshape(ref.shape)
+        assert np.array_equal(got.astype(np.float64), ref.astype(np.float64)), n
+    assert np.array_equal(logits, g["logits_int"])
+    assert np.array_equal(s_head, g["logits_scale"])
+
+
+@pytest.mark.parametrize("fname", ["deit_tiny_b1.npz", "deit_small_b4.npz"])
+def test_deit_logits_and_site_checksums(fname):
+    g = load_golden(fname)
+    cfg = iv.CONFIGS[str(g["cfg_name"])]
+    w = iv.make_vit_weights(cfg, int(g["seed"]))
+    assert _digest(w) == str(g["weights_sha256"])
+    o = orc.OracleViT(cfg, w, golden_scales(g))
+    cap = {}
+    logits, _ = o.forward(iv.make_images_int8(cfg, int(g["batch"]), int(g["images_seed"])), cap)
+    assert np.array_equal(logits, g["logits_int"])
+    bad = []
+    for n in g["sites"]:
+        n = str(n)
+        v = cap[n]
+        if n.endswith("norm1") or n.endswith("norm2") or n == "norm":
+            v = np.asarray(v, np.float64)
+        if csum(v) != g["csum/" + n]:
+            bad.append(n)
+    # attn.matmul_2 raw accumulators: the reference's fp32 matmul on non-integer inputs
+    # >= 2^22 is itself inexact (DESIGN.md "numerics contract"); every other site and the
+    # integers derived downstream of matmul_2 must match exactly.
+    assert all(b.endswith("attn.matmul_2") for b in bad), bad
