@@ -1,0 +1,128 @@
+"""ctypes binding of the C-ABI in include/ivit.h (libivit_hip.so, built in-tree).
+
+The product path has NO CPU fallback: if the HIP library is missing or a call
+fails, an exception is raised.
+"""
+import ctypes
+import os
+import subprocess
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+SO_PATH = os.path.join(_CSRC, "libivit_hip.so")
+SOURCES = ["ivit_hip.hip", "ivit_device.h", "ivit_gemm.h", "ivit_elementwise.h", "ivit_attention.h"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+
+
+class IvitError(RuntimeError):
+    pass
+
+
+class Dyadic(ctypes.Structure):
+    """struct ivit_dyadic {double m; double r;}"""
+    _fields_ = [("m", ctypes.c_double), ("r", ctypes.c_double)]
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP extension for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(_CSRC, s) for s in SOURCES if os.path.exists(os.path.join(_CSRC, s))]
+    hdr = os.path.join(os.path.dirname(_CSRC), "..", "include", "ivit.h")
+    newest = max(os.path.getmtime(p) for p in srcs + [hdr])
+    if not force and os.path.exists(SO_PATH) and os.path.getmtime(SO_PATH) >= newest:
+        return SO_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + HIPCC_FLAGS + [os.path.join(_CSRC, "ivit_hip.hip"), "-o", SO_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return SO_PATH
+
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_L = ctypes.c_int64
+_F = ctypes.c_float
+
+# name -> argtypes (all return int status); mirrors include/ivit.h
+SIGNATURES = {
+    "ivit_create": [ctypes.POINTER(_P), _I, _P],
+    "ivit_destroy": [_P],
+    "ivit_set_stream": [_P, _P],
+    "ivit_quantize_input_f32": [_P, _P, _F, _P, _L],
+    "ivit_linear_i8": [_P, _P, _P, _P, _P, _I, _I, _I],
+    "ivit_linear_i8_requant": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I],
+    "ivit_linear_i8_requant_residual": [_P, _P, _P, _P, _P, Dyadic, Dyadic, _P, _P, _I, _I, _I],
+    "ivit_linear_i8_qkv": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I],
+    "ivit_bmm_nt_i8": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _L, _L],
+    "ivit_bmm_nt_u16i8": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _L, _L],
+    "ivit_attn_qk_requant": [_P, _P, _P, Dyadic, _P, _I, _I, _I, _I],
+    "ivit_attn_pv_requant": [_P, _P, _P, Dyadic, _P, _I, _I, _I, _I, _I, _I],
+    "ivit_requant_i32": [_P, _P, _P, _I, _P, _P, _I, _P, _L, _I],
+    "ivit_requant_f32": [_P, _P, _P, _I, _P, _P, _I, _P, _L, _I],
+    "ivit_shiftmax": [_P, _P, _L, _I, _I, _F, _I, _P, _I],
+    "ivit_shiftgelu": [_P, _P, _L, _I, _F, _P],
+    "ivit_shiftgelu_requant": [_P, _P, _L, _I, _F, Dyadic, _P],
+    "ivit_layernorm": [_P, _P, _L, _I, _F, _P, _P, _P],
+    "ivit_layernorm_requant": [_P, _P, _L, _I, _L, _F, _P, _P, _P, _P],
+    "ivit_im2col_patch": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "ivit_embed_finish": [_P, _P, _P, _P, Dyadic, Dyadic, _P, _I, _I, _I],
+}
+OTHER_SYMBOLS = ["ivit_version", "ivit_status_string", "ivit_last_error"]
+
+_lib = None
+
+
+def load():
+    """dlopen the in-tree library; raises IvitError if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise IvitError(f"{SO_PATH} not built — run `python -c 'import __graft_entry__ as g; g.build()'`; "
+                        "there is no CPU fallback for the product path")
+    lib = ctypes.CDLL(SO_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = ctypes.c_int
+    lib.ivit_version.restype = ctypes.c_int
+    lib.ivit_status_string.restype = ctypes.c_char_p
+    lib.ivit_status_string.argtypes = [ctypes.c_int]
+    lib.ivit_last_error.restype = ctypes.c_char_p
+    lib.ivit_last_error.argtypes = [_P]
+    _lib = lib
+    return lib
+
+
+class Handle:
+    """ivit_handle bound to (device, HIP stream)."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = load()
+        h = _P()
+        st = self.lib.ivit_create(ctypes.byref(h), int(device), _P(stream or 0))
+        if st != 0:
+            raise IvitError(f"ivit_create(device={device}): {self.lib.ivit_status_string(st).decode()}")
+        self.h = h
+        self.device = device
+
+    def set_stream(self, stream):
+        self._check(self.lib.ivit_set_stream(self.h, _P(stream or 0)), "ivit_set_stream")
+
+    def _check(self, st, name):
+        if st != 0:
+            raise IvitError(f"{name}: {self.lib.ivit_status_string(st).decode()} "
+                            f"({self.lib.ivit_last_error(self.h).decode()})")
+
+    def call(self, name, *args):
+        self._check(getattr(self.lib, name)(self.h, *args), name)
+
+    def close(self):
+        if self.h:
+            self.lib.ivit_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,112 @@
+// ivit_device.h — device-side building blocks shared by the gfx950 kernels.
+//
+// Numerics contract (DESIGN.md §"numerics contract"):
+//   * contractions are exact int32 (MFMA i8);
+//   * dyadic requantisation is the reference's fp64 sequence
+//       rne( (double(z) * m) * 2^-e )            (quant_utils.py:229-230)
+//   * Shiftmax / ShiftGELU / I-LayerNorm interiors are binary32 sequences whose
+//     individual roundings matter: this translation unit is built with
+//     -ffp-contract=off, IEEE division (hipcc default) and no fast-math.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/ivit.h"
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef short v8s __attribute__((ext_vector_type(8)));
+
+#define IVIT_WAVE 64
+
+// ---- dyadic requant -------------------------------------------------------
+__device__ __forceinline__ double rq_f64(double z, double m, double r) {
+    return __builtin_rint((z * m) * r);
+}
+// output.type(torch.float) then clamp (quant_utils.py:247-251); lo/hi are small
+// powers of two so clamping in double before the cast is equivalent.
+__device__ __forceinline__ int clamp_bits(double v, int bits) {
+    const double hi = (double)((1ll << (bits - 1)) - 1), lo = -hi - 1.0;
+    v = v < lo ? lo : (v > hi ? hi : v);
+    return (int)v;
+}
+template <int BITS>
+__device__ __forceinline__ int clamp_b(double v) {
+    constexpr double hi = (double)((1ll << (BITS - 1)) - 1), lo = -hi - 1.0;
+    v = v < lo ? lo : (v > hi ? hi : v);
+    return (int)v;
+}
+
+// ---- fp32-faithful pieces ---------------------------------------------------
+// value a consumer of (Q, s) sees: fl(fl(Q*s)/s)   (quant_modules.py:204-206 then
+// :94/:359/:426/:484).  Not always equal to Q.
+__device__ __forceinline__ float requotient(float q, float s) {
+    float X = q * s;
+    return X / s;
+}
+
+// int_exp_shift of Shiftmax/ShiftGELU (quant_modules.py:410-423, 469-481).
+// x: fp32 "integer" (<= 0 except the exp(-max) call of ShiftGELU);
+// x0 = floor(-1/s); nx0 = fl(n*x0).
+__device__ __forceinline__ float shift_exp(float x, float x0, float nx0, int n) {
+    float t = x + floorf(x * 0.5f);       // x/2: exact scaling
+    t = t - floorf(x * 0.0625f);          // x/2**4
+    t = fmaxf(t, nx0);
+    float q = floorf(t / x0);
+    float r = t - x0 * q;
+    float e = r * 0.5f - x0;
+    e = floorf(ldexpf(e, n - (int)q));    // e * 2**(n-q): exact scaling (or inf)
+    return fmaxf(e, 0.0f);
+}
+
+// factor = floor((2**31-1)/S): python-int / tensor = reciprocal * fl32(2^31-1)=2^31
+__device__ __forceinline__ float recip_factor(float S) {
+    S = fminf(S, 2147483648.0f);          // clamp_max_(2**31-1) in fp32
+    return floorf((1.0f / S) * 2147483648.0f);
+}
+
+// ---- torch-CPU summation order over a contiguous fp32 row -------------------
+// ATen SumKernel (vectorized_inner_sum -> row_sum -> multi_row_sum): 8-lane
+// vectors, 4 interleaved accumulators, 4-level cascade with 16-step levels.
+// 32 consecutive GPU lanes own the 32 (ilp k, vector lane l) accumulators:
+// sub = k*8 + l  reads element 32*i + sub.  `elem(idx)` returns the row's value.
+// Every one of the 32 lanes returns the full sum.  `sub` = lane index in [0,32).
+template <typename F>
+__device__ __forceinline__ float torch_order_sum32(int n, int sub, F elem) {
+    const int nvec = n >> 3;
+    const int size = nvec >> 2;           // steps of 32 elements
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int i = 0;
+    // level_power = max(4, CeilLog2(size)/4) = 4 for every size < 2^20
+    for (; i + 16 <= size;) {
+        for (int j = 0; j < 16; ++j, ++i) a0 += elem(32 * i + sub);
+        a1 += a0; a0 = 0.f;
+        if ((i & 0xF0) != 0) continue;
+        a2 += a1; a1 = 0.f;
+        if ((i & 0xF00) != 0) continue;
+        a3 += a2; a2 = 0.f;
+    }
+    for (; i < size; ++i) a0 += elem(32 * i + sub);
+    a0 += a1; a0 += a2; a0 += a3;
+    // leftover whole vectors go to accumulator k = 0
+    for (int v = size * 4; v < nvec; ++v) {
+        float x = (sub < 8) ? elem(v * 8 + sub) : 0.f;
+        a0 += x;                            // lanes >= 8 add 0 to an unused value... see below
+    }
+    // NOTE: for sub >= 8 the "+= 0.f" above must not perturb a0: x + 0.0f == x for all
+    // finite x (and -0.0f + 0.0f = 0.0f compares equal; sums here are never -0).
+    // combine the 4 ilp accumulators in order k = 1,2,3 (vector adds)
+    float p = a0;
+    p += __shfl(a0, (sub & 7) + 8, 32);
+    p += __shfl(a0, (sub & 7) + 16, 32);
+    p += __shfl(a0, (sub & 7) + 24, 32);
+    // p is valid where sub < 8 (lane l's partial); scalar tail first, then lanes 0..7
+    float fin = 0.f;
+    for (int k = nvec * 8; k < n; ++k) fin += elem(k);
+    if (nvec > 0) {
+#pragma unroll
+        for (int l = 0; l < 8; ++l) fin += __shfl(p, l, 32);
+    }
+    return fin;
+}

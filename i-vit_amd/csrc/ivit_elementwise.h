@@ -1,0 +1,304 @@
+// ivit_elementwise.h — wavefront-reduction + shift kernels for gfx950:
+// I-LayerNorm(+requant), Shiftmax, ShiftGELU(+requant), dyadic requant, patch
+// gather, embedding finish, input quantisation.  All are HBM-bound streaming
+// kernels: 16-byte coalesced loads/stores, rows staged in LDS where the torch
+// summation order needs strided re-reads.
+#pragma once
+#include "ivit_device.h"
+
+// ---------------------------------------------------------------------------
+// a4: input quantisation (quant_utils.py:12-48,77-96)
+__global__ __launch_bounds__(256) void quantize_input_kernel(const float *__restrict__ x, float scale,
+                                                             int8_t *__restrict__ q, long long n) {
+    const float inv = 1.0f / scale;
+    long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    const long long stride = (long long)gridDim.x * 256 * 4;
+    for (; i < n; i += stride) {
+        if (i + 4 <= n) {
+            v4f v = *reinterpret_cast<const v4f *>(x + i);
+            unsigned pack = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float r = rintf(inv * v[e]);
+                r = fminf(fmaxf(r, -128.f), 127.f);
+                pack |= ((unsigned)((int)r) & 0xffu) << (8 * e);
+            }
+            *reinterpret_cast<unsigned *>(q + i) = pack;
+        } else {
+            for (long long j = i; j < n; ++j) {
+                float r = rintf(inv * x[j]);
+                r = fminf(fmaxf(r, -128.f), 127.f);
+                q[j] = (int8_t)(int)r;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// a3: generic dyadic requant (quant_utils.py:213-253); one thread per element group
+template <typename ZT, int BITS>
+__global__ __launch_bounds__(256) void requant_kernel(const ZT *__restrict__ z, const ivit_dyadic *__restrict__ dy,
+                                                      int nch, const int32_t *__restrict__ z_id,
+                                                      const ivit_dyadic *__restrict__ dy_id, void *__restrict__ out,
+                                                      long long total, int C) {
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long stride = (long long)gridDim.x * 256;
+    ivit_dyadic did = {0.0, 0.0};
+    if (z_id) did = dy_id[0];
+    for (; i < total; i += stride) {
+        int c = (int)(i % C);
+        ivit_dyadic d = dy[nch == 1 ? 0 : c];
+        double o = rq_f64((double)z[i], d.m, d.r);
+        if (z_id) o = rq_f64((double)z_id[i], did.m, did.r) + o;
+        int v = clamp_b<BITS>(o);
+        if (BITS == 8) reinterpret_cast<int8_t *>(out)[i] = (int8_t)v;
+        else if (BITS == 16) reinterpret_cast<int16_t *>(out)[i] = (int16_t)v;
+        else reinterpret_cast<int32_t *>(out)[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// a7 (+a3): I-LayerNorm (quant_modules.py:353-386).  32 lanes per row (two rows per
+// wavefront, 8 rows per 256-thread block); the row's fl(fl(Q*s)/s) values are staged
+// in LDS as fp32 so the two torch-order sums can stride through them.
+// OUT8: fused per-channel requant to int8; else write z as float.
+template <bool OUT8>
+__global__ __launch_bounds__(256) void layernorm_kernel(const int16_t *__restrict__ x, long long rows, int C,
+                                                        long long row_stride, float s,
+                                                        const float *__restrict__ bias_int,
+                                                        const float *__restrict__ sc,
+                                                        const ivit_dyadic *__restrict__ dy,
+                                                        void *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char dsmem[];
+    const int sub = threadIdx.x & 31;
+    const int rslot = threadIdx.x >> 5;            // 0..7
+    float *xr = reinterpret_cast<float *>(dsmem) + (size_t)rslot * C;
+    const long long row = (long long)blockIdx.x * 8 + rslot;
+    if (row >= rows) return;                        // whole 32-lane group exits together
+    const int16_t *xp = x + row * row_stride;
+    const float Cf = (float)C;
+
+    // pass 0: coalesced 16-byte loads -> fl(fl(Q*s)/s) -> LDS
+    const int nch8 = C >> 3;
+    for (int c = sub; c < nch8; c += 32) {
+        v8s q = *reinterpret_cast<const v8s *>(xp + c * 8);
+        v4f lo, hi;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            lo[e] = requotient((float)q[e], s);
+            hi[e] = requotient((float)q[4 + e], s);
+        }
+        *reinterpret_cast<v4f *>(xr + c * 8) = lo;
+        *reinterpret_cast<v4f *>(xr + c * 8 + 4) = hi;
+    }
+    for (int k = nch8 * 8 + sub; k < C; k += 32) xr[k] = requotient((float)xp[k], s);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+    float sum = torch_order_sum32(C, sub, [&](int idx) { return xr[idx]; });
+    const float mean = rintf(sum / Cf);
+    float var = torch_order_sum32(C, sub, [&](int idx) {
+        float y = xr[idx] - mean;
+        return y * y;
+    });
+    float k = 65536.0f;
+#pragma unroll
+    for (int it = 0; it < 10; ++it) k = floorf((k + floorf(var / k)) * 0.5f);
+    const float F = floorf((1.0f / k) * 2147483648.0f);
+
+    // output pass: 8 consecutive channels per lane
+    for (int c = sub; c < nch8; c += 32) {
+        v4f a = *reinterpret_cast<const v4f *>(xr + c * 8);
+        v4f b = *reinterpret_cast<const v4f *>(xr + c * 8 + 4);
+        v4f bi0 = *reinterpret_cast<const v4f *>(bias_int + c * 8);
+        v4f bi1 = *reinterpret_cast<const v4f *>(bias_int + c * 8 + 4);
+        v4f sc0 = *reinterpret_cast<const v4f *>(sc + c * 8);
+        v4f sc1 = *reinterpret_cast<const v4f *>(sc + c * 8 + 4);
+        float zz[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float xv = e < 4 ? a[e] : b[e - 4];
+            float bi = e < 4 ? bi0[e] : bi1[e - 4];
+            float scv = e < 4 ? sc0[e] : sc1[e - 4];
+            float y = xv - mean;
+            float yi = floorf((y * F) * 0.5f);
+            float o = yi + bi;
+            float Xo = o * scv;
+            zz[e] = rintf(Xo / scv);
+        }
+        if (OUT8) {
+            unsigned pk[2] = {0, 0};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                ivit_dyadic d = dy[c * 8 + e];
+                int v = clamp_b<8>(rq_f64((double)zz[e], d.m, d.r));
+                pk[e >> 2] |= ((unsigned)v & 0xffu) << (8 * (e & 3));
+            }
+            *reinterpret_cast<v2i *>(reinterpret_cast<int8_t *>(out) + row * C + c * 8) = v2i{(int)pk[0], (int)pk[1]};
+        } else {
+            float *zo = reinterpret_cast<float *>(out) + row * C + c * 8;
+            *reinterpret_cast<v4f *>(zo) = v4f{zz[0], zz[1], zz[2], zz[3]};
+            *reinterpret_cast<v4f *>(zo + 4) = v4f{zz[4], zz[5], zz[6], zz[7]};
+        }
+    }
+    for (int kx = nch8 * 8 + sub; kx < C; kx += 32) {
+        float y = xr[kx] - mean;
+        float yi = floorf((y * F) * 0.5f);
+        float o = yi + bias_int[kx];
+        float Xo = o * sc[kx];
+        float zv = rintf(Xo / sc[kx]);
+        if (OUT8) {
+            ivit_dyadic d = dy[kx];
+            reinterpret_cast<int8_t *>(out)[row * C + kx] = (int8_t)clamp_b<8>(rq_f64((double)zv, d.m, d.r));
+        } else {
+            reinterpret_cast<float *>(out)[row * C + kx] = zv;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// a5: Shiftmax (quant_modules.py:469-497).  One wavefront per row; the row's exp
+// values are staged in LDS (fp32) for the torch-order sum done by lanes 0..31.
+__global__ __launch_bounds__(256) void shiftmax_kernel(const int8_t *__restrict__ x, long long rows, int n,
+                                                       int ld_in, float s, int out_bits,
+                                                       uint16_t *__restrict__ out, int ld_out) {
+    extern __shared__ __attribute__((aligned(16))) char dsmem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *er = reinterpret_cast<float *>(dsmem) + (size_t)wave * n;
+    const long long row = (long long)blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    const int8_t *xp = x + row * ld_in;
+    // row max: fl(fl(Q*s)/s) is monotone in Q (s > 0), so take the integer max first
+    int qmax = -128;
+    for (int j = lane; j < n; j += 64) qmax = max(qmax, (int)xp[j]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) qmax = max(qmax, __shfl_xor(qmax, o));
+    const float mx = requotient((float)qmax, s);
+    const float x0 = floorf(-1.0f / s);
+    const float nx0 = 15.0f * x0;
+    for (int j = lane; j < n; j += 64) {
+        float xt = requotient((float)xp[j], s);
+        er[j] = shift_exp(xt - mx, x0, nx0, 15);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    float S = torch_order_sum32(n, lane & 31, [&](int idx) { return er[idx]; });
+    const float F = recip_factor(S);
+    const float div = ldexpf(1.0f, out_bits - 32);  // 1 / 2**(31-bits+1), exact
+    uint16_t *op = out + row * ld_out;
+    for (int j = lane; j < n; j += 64) op[j] = (uint16_t)(int)floorf((er[j] * F) * div);
+}
+
+// ---------------------------------------------------------------------------
+// a6 (+a3): ShiftGELU (quant_modules.py:410-445).  One wavefront per token row.
+template <bool OUT8>
+__global__ __launch_bounds__(256) void shiftgelu_kernel(const int8_t *__restrict__ x, long long rows, int C, float s,
+                                                        ivit_dyadic dy, void *__restrict__ out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long row = (long long)blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    const int8_t *xp = x + row * C;
+    const int nch = C >> 4;
+    int qmax = -128;
+    for (int c = lane; c < nch; c += 64) {
+        v4i v = *reinterpret_cast<const v4i *>(xp + c * 16);
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) qmax = max(qmax, (int)(int8_t)((unsigned)v[d] >> (8 * b)));
+    }
+    for (int k = nch * 16 + lane; k < C; k += 64) qmax = max(qmax, (int)xp[k]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) qmax = max(qmax, __shfl_xor(qmax, o));
+    const float mx = requotient((float)qmax, s);
+    const float ssig = s * 1.702f;
+    const float x0 = floorf(-1.0f / ssig);
+    const float nx0 = 23.0f * x0;
+    const float emax = shift_exp(-mx, x0, nx0, 23);
+
+    auto one = [&](int q) -> int {
+        float p = requotient((float)q, s);
+        float e = shift_exp(p - mx, x0, nx0, 23);
+        float F = recip_factor(e + emax);
+        float sig = floorf((e * F) * 5.9604644775390625e-08f);  // / 2**24
+        // next QuantAct rounds p*sig back to the integer Q*sig (quant_utils.py:220)
+        int prod = (int)rintf(p * sig);
+        if (OUT8) return clamp_b<8>(rq_f64((double)prod, dy.m, dy.r));
+        return prod;
+    };
+
+    for (int c = lane; c < nch; c += 64) {
+        v4i v = *reinterpret_cast<const v4i *>(xp + c * 16);
+        if (OUT8) {
+            v4i o;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                unsigned pk = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    pk |= ((unsigned)one((int)(int8_t)((unsigned)v[d] >> (8 * b))) & 0xffu) << (8 * b);
+                o[d] = (int)pk;
+            }
+            *reinterpret_cast<v4i *>(reinterpret_cast<int8_t *>(out) + row * C + c * 16) = o;
+        } else {
+            int16_t *op = reinterpret_cast<int16_t *>(out) + row * C + c * 16;
+            v4i o0, o1;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                int r0 = one((int)(int8_t)((unsigned)v[d])), r1 = one((int)(int8_t)((unsigned)v[d] >> 8));
+                int r2 = one((int)(int8_t)((unsigned)v[d] >> 16)), r3 = one((int)(int8_t)((unsigned)v[d] >> 24));
+                int w0 = (r0 & 0xffff) | (r1 << 16), w1 = (r2 & 0xffff) | (r3 << 16);
+                if (d < 2) { o0[2 * d] = w0; o0[2 * d + 1] = w1; }
+                else { o1[2 * (d - 2)] = w0; o1[2 * (d - 2) + 1] = w1; }
+            }
+            *reinterpret_cast<v4i *>(op) = o0;
+            *reinterpret_cast<v4i *>(op + 8) = o1;
+        }
+    }
+    for (int k = nch * 16 + lane; k < C; k += 64) {
+        int r = one((int)xp[k]);
+        if (OUT8) reinterpret_cast<int8_t *>(out)[row * C + k] = (int8_t)r;
+        else reinterpret_cast<int16_t *>(out)[row * C + k] = (int16_t)r;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// a8: patch gather (layers_quant.py:184-196): NCHW int8 -> [B*gh*gw, Cin*P*P],
+// element order (c, py, px) = conv weight order.  One thread per 4 output bytes.
+__global__ __launch_bounds__(256) void im2col_patch_kernel(const int8_t *__restrict__ img, int B, int Cin, int H,
+                                                           int W, int P, int8_t *__restrict__ rows) {
+    const int gh = H / P, gw = W / P, K = Cin * P * P;
+    const long long total4 = (long long)B * gh * gw * K / 4;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long stride = (long long)gridDim.x * 256;
+    for (; i < total4; i += stride) {
+        long long e = i * 4;
+        int kk = (int)(e % K);
+        long long prow = e / K;
+        int gx = (int)(prow % gw);
+        int gy = (int)((prow / gw) % gh);
+        int b = (int)(prow / ((long long)gw * gh));
+        int px = kk % P, py = (kk / P) % P, c = kk / (P * P);
+        const int8_t *src = img + (((long long)b * Cin + c) * H + gy * P + py) * W + gx * P + px;
+        *reinterpret_cast<int *>(rows + e) = *reinterpret_cast<const int *>(src);
+    }
+}
+
+// class token + position embedding (vit_quant.py:259-265)
+__global__ __launch_bounds__(256) void embed_finish_kernel(const int16_t *__restrict__ patch16,
+                                                           const int32_t *__restrict__ z_cls,
+                                                           const int16_t *__restrict__ pos, ivit_dyadic dx,
+                                                           ivit_dyadic dp, int16_t *__restrict__ x16, int B, int T,
+                                                           int D) {
+    const long long total = (long long)B * T * D;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long stride = (long long)gridDim.x * 256;
+    for (; i < total; i += stride) {
+        int d = (int)(i % D);
+        int t = (int)((i / D) % T);
+        int b = (int)(i / ((long long)D * T));
+        int z = t == 0 ? z_cls[d] : (int)patch16[((long long)b * (T - 1) + (t - 1)) * D + d];
+        double o = rq_f64((double)pos[(long long)t * D + d], dp.m, dp.r) + rq_f64((double)z, dx.m, dx.r);
+        x16[i] = (int16_t)clamp_b<16>(o);
+    }
+}

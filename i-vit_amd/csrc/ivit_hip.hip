@@ -1,0 +1,338 @@
+// ivit_hip.hip — C-ABI (include/ivit.h) over the gfx950 kernels.
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include "ivit_device.h"
+#include "ivit_elementwise.h"
+#include "ivit_gemm.h"
+
+struct ivit_ctx {
+    int device;
+    hipStream_t stream;
+    int num_cu;
+    char err[256];
+};
+
+#define CHECK_H(h) do { if (!(h)) return IVIT_ERR_INVALID; } while (0)
+#define REQUIRE(h, cond, msg) do { if (!(cond)) { snprintf((h)->err, sizeof((h)->err), "%s: %s", __func__, msg); return IVIT_ERR_INVALID; } } while (0)
+#define LAUNCH_CHECK(h) do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { snprintf((h)->err, sizeof((h)->err), "%s: %s", __func__, hipGetErrorString(e_)); return IVIT_ERR_HIP; } } while (0)
+
+extern "C" {
+
+int ivit_version(void) { return 100; }
+
+const char *ivit_status_string(int s) {
+    switch (s) {
+        case IVIT_OK: return "ok";
+        case IVIT_ERR_INVALID: return "invalid argument";
+        case IVIT_ERR_HIP: return "HIP runtime error";
+        case IVIT_ERR_UNSUPPORTED: return "unsupported shape";
+        case IVIT_ERR_NO_DEVICE: return "no HIP device";
+        default: return "unknown status";
+    }
+}
+
+int ivit_create(ivit_handle *out, int device, void *hip_stream) {
+    if (!out) return IVIT_ERR_INVALID;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return IVIT_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return IVIT_ERR_HIP;
+    ivit_ctx *c = new ivit_ctx();
+    c->device = device;
+    c->stream = (hipStream_t)hip_stream;
+    c->err[0] = 0;
+    hipDeviceProp_t prop;
+    c->num_cu = (hipGetDeviceProperties(&prop, device) == hipSuccess) ? prop.multiProcessorCount : 256;
+    *out = c;
+    return IVIT_OK;
+}
+
+int ivit_destroy(ivit_handle h) {
+    CHECK_H(h);
+    delete h;
+    return IVIT_OK;
+}
+
+int ivit_set_stream(ivit_handle h, void *hip_stream) {
+    CHECK_H(h);
+    h->stream = (hipStream_t)hip_stream;
+    return IVIT_OK;
+}
+
+const char *ivit_last_error(ivit_handle h) { return h ? h->err : "null handle"; }
+
+static inline int grid_for(ivit_handle h, long long work_items, int per_block) {
+    long long g = (work_items + per_block - 1) / per_block;
+    long long cap = (long long)h->num_cu * 16;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+int ivit_quantize_input_f32(ivit_handle h, const float *x, float scale, int8_t *q, int64_t n) {
+    CHECK_H(h);
+    REQUIRE(h, x && q && n >= 0 && scale > 0.f, "bad arguments");
+    if (n == 0) return IVIT_OK;
+    quantize_input_kernel<<<grid_for(h, n, 1024), 256, 0, h->stream>>>(x, scale, q, n);
+    LAUNCH_CHECK(h);
+    return IVIT_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------- GEMM launchers
+template <bool A16, int EPI>
+static int launch_gemm(ivit_handle h, GemmArgs &a, int nb) {
+    const int tm = (a.M + GEMM_BM - 1) / GEMM_BM;
+    a.tiles_n = (a.N + GEMM_BN - 1) / GEMM_BN;
+    dim3 grid((unsigned)(tm * a.tiles_n), (unsigned)nb, 1);
+    gemm_nt_kernel<A16, EPI><<<grid, 256, 0, h->stream>>>(a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(h->err, sizeof(h->err), "gemm launch: %s", hipGetErrorString(e));
+        return IVIT_ERR_HIP;
+    }
+    return IVIT_OK;
+}
+
+static GemmArgs linear_args(const int8_t *x, const int8_t *w, const int32_t *bias, int M, int N, int K) {
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A = x; a.B = w; a.M = M; a.N = N; a.K = K;
+    a.lda = K; a.ldb = K; a.ldc = N;
+    a.inner = 1; a.bias = bias;
+    return a;
+}
+
+extern "C" {
+
+int ivit_linear_i8(ivit_handle h, const int8_t *x, const int8_t *w, const int32_t *bias, int32_t *acc,
+                   int M, int N, int K) {
+    CHECK_H(h);
+    REQUIRE(h, x && w && acc && M > 0 && N > 0 && K > 0, "bad arguments");
+    REQUIRE(h, (K % 16) == 0, "K must be a multiple of 16");
+    GemmArgs a = linear_args(x, w, bias, M, N, K);
+    a.out = acc;
+    return launch_gemm<false, EPI_RAW32>(h, a, 1);
+}
+
+int ivit_linear_i8_requant(ivit_handle h, const int8_t *x, const int8_t *w, const int32_t *bias,
+                           const ivit_dyadic *dy_ch, int bits, void *out, int M, int N, int K) {
+    CHECK_H(h);
+    REQUIRE(h, x && w && out && dy_ch && M > 0 && N > 0 && K > 0, "bad arguments");
+    REQUIRE(h, (K % 16) == 0, "K must be a multiple of 16");
+    REQUIRE(h, bits == 8 || bits == 16, "bits must be 8 or 16");
+    GemmArgs a = linear_args(x, w, bias, M, N, K);
+    a.out = out; a.dy_ch = dy_ch;
+    return bits == 8 ? launch_gemm<false, EPI_RQ8_CH>(h, a, 1) : launch_gemm<false, EPI_RQ16_CH>(h, a, 1);
+}
+
+int ivit_linear_i8_requant_residual(ivit_handle h, const int8_t *x, const int8_t *w, const int32_t *bias,
+                                    const ivit_dyadic *dy_ch, ivit_dyadic dy_main, ivit_dyadic dy_res,
+                                    const int16_t *residual, int16_t *out, int M, int N, int K) {
+    CHECK_H(h);
+    REQUIRE(h, x && w && out && dy_ch && residual && M > 0 && N > 0 && K > 0, "bad arguments");
+    REQUIRE(h, (K % 16) == 0, "K must be a multiple of 16");
+    GemmArgs a = linear_args(x, w, bias, M, N, K);
+    a.out = out; a.dy_ch = dy_ch; a.dy_main = dy_main; a.dy_res = dy_res; a.residual = residual;
+    return launch_gemm<false, EPI_RQ16_CH_RES>(h, a, 1);
+}
+
+int ivit_linear_i8_qkv(ivit_handle h, const int8_t *x, const int8_t *w, const int32_t *bias,
+                       const ivit_dyadic *dy_ch, int8_t *q, int8_t *k, int8_t *vt, int B, int T, int H,
+                       int dh, int ldv) {
+    CHECK_H(h);
+    REQUIRE(h, x && w && dy_ch && q && k && vt && B > 0 && T > 0 && H > 0 && dh > 0, "bad arguments");
+    REQUIRE(h, (dh % 16) == 0, "head dim must be a multiple of 16");
+    REQUIRE(h, ldv >= T, "ldv < T");
+    const int D = H * dh;
+    GemmArgs a = linear_args(x, w, bias, B * T, 3 * D, D);
+    a.dy_ch = dy_ch; a.q = q; a.k = k; a.vt = vt;
+    a.T = T; a.H = H; a.dh = dh; a.ldv = ldv; a.D = D;
+    return launch_gemm<false, EPI_QKV>(h, a, 1);
+}
+
+int ivit_bmm_nt_i8(ivit_handle h, const int8_t *A, const int8_t *B, int32_t *C, int nb, int M, int N, int K,
+                   int lda, int ldb, int ldc, int64_t strideA, int64_t strideB, int64_t strideC) {
+    CHECK_H(h);
+    REQUIRE(h, A && B && C && nb > 0 && M > 0 && N > 0 && K > 0, "bad arguments");
+    REQUIRE(h, (lda % 16) == 0 && (ldb % 16) == 0 && (strideA % 16) == 0 && (strideB % 16) == 0,
+            "lda/ldb/strides must be multiples of 16");
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A = A; a.B = B; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+    a.strideA = strideA; a.strideB = strideB; a.inner = 1; a.sC_outer = strideC; a.out = C;
+    return launch_gemm<false, EPI_RAW32>(h, a, nb);
+}
+
+int ivit_bmm_nt_u16i8(ivit_handle h, const uint16_t *A, const int8_t *B, int32_t *C, int nb, int M, int N,
+                      int K, int lda, int ldb, int ldc, int64_t strideA, int64_t strideB, int64_t strideC) {
+    CHECK_H(h);
+    REQUIRE(h, A && B && C && nb > 0 && M > 0 && N > 0 && K > 0, "bad arguments");
+    REQUIRE(h, (lda % 8) == 0 && (ldb % 16) == 0 && (strideA % 8) == 0 && (strideB % 16) == 0,
+            "lda must be a multiple of 8, ldb of 16");
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A = A; a.B = B; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+    a.strideA = strideA; a.strideB = strideB; a.inner = 1; a.sC_outer = strideC; a.out = C;
+    return launch_gemm<true, EPI_RAW32>(h, a, nb);
+}
+
+int ivit_attn_qk_requant(ivit_handle h, const int8_t *q, const int8_t *k, ivit_dyadic dy, int8_t *scores8,
+                         int BH, int T, int dh, int lds) {
+    CHECK_H(h);
+    REQUIRE(h, q && k && scores8 && BH > 0 && T > 0 && dh > 0, "bad arguments");
+    REQUIRE(h, (dh % 16) == 0 && lds >= T, "dh %16, lds >= T");
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A = q; a.B = k; a.M = T; a.N = T; a.K = dh; a.lda = dh; a.ldb = dh; a.ldc = lds;
+    a.strideA = (long long)T * dh; a.strideB = (long long)T * dh;
+    a.inner = 1; a.sC_outer = (long long)T * lds; a.out = scores8; a.dy_main = dy;
+    return launch_gemm<false, EPI_RQ8_S>(h, a, BH);
+}
+
+int ivit_attn_pv_requant(ivit_handle h, const uint16_t *p, const int8_t *vt, ivit_dyadic dy, int8_t *ctx8,
+                         int B, int H, int T, int dh, int ldp, int ldv) {
+    CHECK_H(h);
+    REQUIRE(h, p && vt && ctx8 && B > 0 && H > 0 && T > 0 && dh > 0, "bad arguments");
+    REQUIRE(h, (ldp % 8) == 0 && (ldv % 16) == 0 && ldp >= T && ldv >= T, "ldp %8, ldv %16, >= T");
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A = p; a.B = vt; a.M = T; a.N = dh; a.K = T; a.lda = ldp; a.ldb = ldv; a.ldc = H * dh;
+    a.strideA = (long long)T * ldp; a.strideB = (long long)dh * ldv;
+    a.inner = H; a.sC_outer = (long long)T * H * dh; a.sC_inner = dh; a.out = ctx8; a.dy_main = dy;
+    return launch_gemm<true, EPI_RQ8_S>(h, a, B * H);
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------- requant
+template <typename ZT>
+static int requant_any(ivit_handle h, const ZT *z, const ivit_dyadic *dy, int nch, const int32_t *z_id,
+                       const ivit_dyadic *dy_id, int bits, void *out, int64_t rows, int C) {
+    const long long total = (long long)rows * C;
+    const int g = grid_for(h, total, 256 * 4);
+    if (bits == 8) requant_kernel<ZT, 8><<<g, 256, 0, h->stream>>>(z, dy, nch, z_id, dy_id, out, total, C);
+    else if (bits == 16) requant_kernel<ZT, 16><<<g, 256, 0, h->stream>>>(z, dy, nch, z_id, dy_id, out, total, C);
+    else requant_kernel<ZT, 32><<<g, 256, 0, h->stream>>>(z, dy, nch, z_id, dy_id, out, total, C);
+    LAUNCH_CHECK(h);
+    return IVIT_OK;
+}
+
+extern "C" {
+
+int ivit_requant_i32(ivit_handle h, const int32_t *z, const ivit_dyadic *dy, int nch, const int32_t *z_id,
+                     const ivit_dyadic *dy_id, int bits, void *out, int64_t rows, int C) {
+    CHECK_H(h);
+    REQUIRE(h, z && dy && out && rows > 0 && C > 0, "bad arguments");
+    REQUIRE(h, nch == 1 || nch == C, "nch must be 1 or C");
+    REQUIRE(h, bits == 8 || bits == 16 || bits == 32, "bits must be 8, 16 or 32");
+    REQUIRE(h, (z_id == nullptr) == (dy_id == nullptr), "z_id and dy_id go together");
+    return requant_any<int32_t>(h, z, dy, nch, z_id, dy_id, bits, out, rows, C);
+}
+
+int ivit_requant_f32(ivit_handle h, const float *z, const ivit_dyadic *dy, int nch, const int32_t *z_id,
+                     const ivit_dyadic *dy_id, int bits, void *out, int64_t rows, int C) {
+    CHECK_H(h);
+    REQUIRE(h, z && dy && out && rows > 0 && C > 0, "bad arguments");
+    REQUIRE(h, nch == 1 || nch == C, "nch must be 1 or C");
+    REQUIRE(h, bits == 8 || bits == 16 || bits == 32, "bits must be 8, 16 or 32");
+    REQUIRE(h, (z_id == nullptr) == (dy_id == nullptr), "z_id and dy_id go together");
+    return requant_any<float>(h, z, dy, nch, z_id, dy_id, bits, out, rows, C);
+}
+
+// ---------------------------------------------------------------- shift/norm kernels
+static int set_dyn_lds(ivit_handle h, const void *fn, size_t bytes) {
+    if (bytes > 65536) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) {
+            snprintf(h->err, sizeof(h->err), "hipFuncSetAttribute: %s", hipGetErrorString(e));
+            return IVIT_ERR_HIP;
+        }
+    }
+    return IVIT_OK;
+}
+
+int ivit_shiftmax(ivit_handle h, const int8_t *x, int64_t rows, int n, int ld_in, float scale, int out_bits,
+                  uint16_t *out, int ld_out) {
+    CHECK_H(h);
+    REQUIRE(h, x && out && rows > 0 && n > 0 && ld_in >= n && ld_out >= n && scale > 0.f, "bad arguments");
+    REQUIRE(h, out_bits == 8 || out_bits == 16, "out_bits must be 8 or 16");
+    const size_t lds = (size_t)4 * n * sizeof(float);
+    REQUIRE(h, lds <= 160 * 1024, "row too long for LDS staging");
+    int st = set_dyn_lds(h, (const void *)shiftmax_kernel, lds);
+    if (st) return st;
+    shiftmax_kernel<<<(unsigned)((rows + 3) / 4), 256, lds, h->stream>>>(x, rows, n, ld_in, scale, out_bits, out, ld_out);
+    LAUNCH_CHECK(h);
+    return IVIT_OK;
+}
+
+int ivit_shiftgelu(ivit_handle h, const int8_t *x, int64_t rows, int C, float scale, int16_t *out16) {
+    CHECK_H(h);
+    REQUIRE(h, x && out16 && rows > 0 && C > 0 && scale > 0.f, "bad arguments");
+    REQUIRE(h, (C % 16) == 0, "C must be a multiple of 16");
+    ivit_dyadic d = {0.0, 0.0};
+    shiftgelu_kernel<false><<<(unsigned)((rows + 3) / 4), 256, 0, h->stream>>>(x, rows, C, scale, d, out16);
+    LAUNCH_CHECK(h);
+    return IVIT_OK;
+}
+
+int ivit_shiftgelu_requant(ivit_handle h, const int8_t *x, int64_t rows, int C, float scale, ivit_dyadic dy,
+                           int8_t *out8) {
+    CHECK_H(h);
+    REQUIRE(h, x && out8 && rows > 0 && C > 0 && scale > 0.f, "bad arguments");
+    REQUIRE(h, (C % 16) == 0, "C must be a multiple of 16");
+    shiftgelu_kernel<true><<<(unsigned)((rows + 3) / 4), 256, 0, h->stream>>>(x, rows, C, scale, dy, out8);
+    LAUNCH_CHECK(h);
+    return IVIT_OK;
+}
+
+int ivit_layernorm(ivit_handle h, const int16_t *x, int64_t rows, int C, float scale, const float *bias_int,
+                   const float *sc, float *z) {
+    CHECK_H(h);
+    REQUIRE(h, x && bias_int && sc && z && rows > 0 && C > 0 && scale > 0.f, "bad arguments");
+    REQUIRE(h, (C % 8) == 0, "C must be a multiple of 8");
+    const size_t lds = (size_t)8 * C * sizeof(float);
+    REQUIRE(h, lds <= 160 * 1024, "C too large for LDS staging");
+    int st = set_dyn_lds(h, (const void *)layernorm_kernel<false>, lds);
+    if (st) return st;
+    layernorm_kernel<false><<<(unsigned)((rows + 7) / 8), 256, lds, h->stream>>>(x, rows, C, C, scale, bias_int, sc, nullptr, z);
+    LAUNCH_CHECK(h);
+    return IVIT_OK;
+}
+
+int ivit_layernorm_requant(ivit_handle h, const int16_t *x, int64_t rows, int C, int64_t row_stride, float scale,
+                           const float *bias_int, const float *sc, const ivit_dyadic *dy_ch, int8_t *out8) {
+    CHECK_H(h);
+    REQUIRE(h, x && bias_int && sc && dy_ch && out8 && rows > 0 && C > 0 && scale > 0.f, "bad arguments");
+    REQUIRE(h, (C % 8) == 0 && (row_stride % 8) == 0 && row_stride >= C, "C, row_stride multiples of 8");
+    const size_t lds = (size_t)8 * C * sizeof(float);
+    REQUIRE(h, lds <= 160 * 1024, "C too large for LDS staging");
+    int st = set_dyn_lds(h, (const void *)layernorm_kernel<true>, lds);
+    if (st) return st;
+    layernorm_kernel<true><<<(unsigned)((rows + 7) / 8), 256, lds, h->stream>>>(x, rows, C, row_stride, scale, bias_int, sc, dy_ch, out8);
+    LAUNCH_CHECK(h);
+    return IVIT_OK;
+}
+
+int ivit_im2col_patch(ivit_handle h, const int8_t *img, int B, int Cin, int H, int W, int P, int8_t *rows) {
+    CHECK_H(h);
+    REQUIRE(h, img && rows && B > 0 && Cin > 0 && P > 0, "bad arguments");
+    REQUIRE(h, (H % P) == 0 && (W % P) == 0 && (P % 4) == 0 && (W % 4) == 0, "H,W multiples of P; P,W multiples of 4");
+    const long long total4 = (long long)B * H * W * Cin / 4;
+    im2col_patch_kernel<<<grid_for(h, total4, 256), 256, 0, h->stream>>>(img, B, Cin, H, W, P, rows);
+    LAUNCH_CHECK(h);
+    return IVIT_OK;
+}
+
+int ivit_embed_finish(ivit_handle h, const int16_t *patch16, const int32_t *z_cls, const int16_t *pos,
+                      ivit_dyadic dy_x, ivit_dyadic dy_pos, int16_t *x16, int B, int T, int D) {
+    CHECK_H(h);
+    REQUIRE(h, patch16 && z_cls && pos && x16 && B > 0 && T > 1 && D > 0, "bad arguments");
+    embed_finish_kernel<<<grid_for(h, (long long)B * T * D, 256), 256, 0, h->stream>>>(patch16, z_cls, pos, dy_x, dy_pos, x16, B, T, D);
+    LAUNCH_CHECK(h);
+    return IVIT_OK;
+}
+
+}  // extern "C"

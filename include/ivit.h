@@ -1,0 +1,164 @@
+/*
+ * ivit.h — C-ABI of the MI355X-native integer-only ViT inference path.
+ *
+ * The reference (zkkli/I-ViT) has no FFI layer: its boundary for this path is the
+ * Python operator surface of models/quantization_utils/quant_modules.py (re-exported
+ * by models/quantization_utils/__init__.py:1).  Each entry point below names the
+ * reference interface it replaces (file:line, relative to the reference root).  The
+ * Python face that mirrors the reference classes lives in i-vit_amd/quant_modules.py
+ * and binds these symbols with ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - tensors are dense row-major, the channel dimension is last;
+ *   - every call is asynchronous on the handle's HIP stream, allocates nothing,
+ *     synchronises nothing and is hipGraph-capturable;
+ *   - return value: IVIT_OK or an error code (no exceptions, no aborts);
+ *   - activations are carried as INTEGERS plus an fp32 scale held by the caller
+ *     (the reference carries fp32 "integer*scale" tensors; X = fl(Q*s) is
+ *     re-derived inside the kernels where its rounding matters).
+ *
+ * Dyadic requantisation (reference quant_utils.py:150-175, 213-253):
+ *   out = clamp( rne( (double(z) * m) * r ) [+ rne((double(z_id) * m_id) * r_id)] )
+ *   with m = round_half_away(mant * 2^31), r = 2^-(31 - exponent) of
+ *   double(s_pre)/double(float(s_out)); prepared on the host (ivit_amd.freeze).
+ */
+#ifndef IVIT_H
+#define IVIT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ivit_ctx *ivit_handle;
+
+typedef struct ivit_dyadic {
+    double m; /* integer-valued multiplier, |m| <= 2^31 (negative after LN with w<0) */
+    double r; /* 2^-e */
+} ivit_dyadic;
+
+enum {
+    IVIT_OK = 0,
+    IVIT_ERR_INVALID = 1,     /* bad argument (null pointer, size, alignment, bits) */
+    IVIT_ERR_HIP = 2,         /* HIP runtime error, see ivit_last_error            */
+    IVIT_ERR_UNSUPPORTED = 3, /* shape outside what the kernels are built for      */
+    IVIT_ERR_NO_DEVICE = 4
+};
+
+int ivit_version(void);
+const char *ivit_status_string(int status);
+
+/* One handle per (device, stream).  `hip_stream` is a hipStream_t (NULL = default). */
+int ivit_create(ivit_handle *out, int device, void *hip_stream);
+int ivit_destroy(ivit_handle h);
+int ivit_set_stream(ivit_handle h, void *hip_stream);
+const char *ivit_last_error(ivit_handle h);
+
+/* ---- a4  QuantAct.forward, input branch  (quant_modules.py:194-196 ->
+ * quant_utils.py:77-96, 12-48):  q = clamp(rne(fl(fl(1/s)*x)), -128, 127)            */
+int ivit_quantize_input_f32(ivit_handle h, const float *x, float scale, int8_t *q, int64_t n);
+
+/* ---- a1  QuantLinear.forward  (quant_modules.py:67-97) — integer accumulators.
+ * acc[i,j] = sum_k x[i,k]*w[j,k] + bias[j];  x int8 [M,K], w int8 [N,K], K % 16 == 0. */
+int ivit_linear_i8(ivit_handle h, const int8_t *x, const int8_t *w, const int32_t *bias,
+                   int32_t *acc, int M, int N, int K);
+
+/* a1 + a3: the QuantLinear -> QuantAct pairs of the reference, fused.
+ * out = clamp_bits(rq(acc[i,j], dy_ch[j]));  bits = 8 (int8 out) or 16 (int16 out).    */
+int ivit_linear_i8_requant(ivit_handle h, const int8_t *x, const int8_t *w, const int32_t *bias,
+                           const ivit_dyadic *dy_ch, int bits, void *out, int M, int N, int K);
+
+/* a1 + a3 + a3(identity): proj/fc2 -> QuantAct(16) -> Block.qact2/qact4 residual add
+ * (vit_quant.py:84-85,135,141; layers_quant.py:150-151):
+ * t = clamp16(rq(acc, dy_ch[j])); out = clamp16(rq(t, dy_main) + rq(residual, dy_res)). */
+int ivit_linear_i8_requant_residual(ivit_handle h, const int8_t *x, const int8_t *w,
+                                    const int32_t *bias, const ivit_dyadic *dy_ch,
+                                    ivit_dyadic dy_main, ivit_dyadic dy_res,
+                                    const int16_t *residual, int16_t *out, int M, int N, int K);
+
+/* a1 + a3 + head split (vit_quant.py:61-69): qkv Linear -> QuantAct(8) -> q,k as
+ * [B,H,T,dh] and v TRANSPOSED as [B,H,dh,ldv] (token dim contiguous, ldv % 16 == 0,
+ * ldv >= T) — the layout the MFMA attn·v operand wants.  x is [B*T, D], w [3D, D].      */
+int ivit_linear_i8_qkv(ivit_handle h, const int8_t *x, const int8_t *w, const int32_t *bias,
+                       const ivit_dyadic *dy_ch, int8_t *q, int8_t *k, int8_t *vt, int B, int T,
+                       int H, int dh, int ldv);
+
+/* ---- a2  QuantMatMul.forward  (quant_modules.py:223-228), batched, "NT" form:
+ * C[b] = A[b] (M x K) * B[b]^T (B[b] is N x K), int32.  q·kᵀ: A=q, B=k.
+ * lda/ldb/ldc in elements, strides per batch in elements; lda,ldb % 16 == 0.            */
+int ivit_bmm_nt_i8(ivit_handle h, const int8_t *A, const int8_t *B, int32_t *C, int nb, int M,
+                   int N, int K, int lda, int ldb, int ldc, int64_t strideA, int64_t strideB,
+                   int64_t strideC);
+/* attn·v with the 16-bit Shiftmax output as A (values 0..32768): exact, two int8 MFMA
+ * passes (a-16384 = 256*hi + lo) + 16384*colsum(B).  B = vᵀ [N=dh, K=T].                */
+int ivit_bmm_nt_u16i8(ivit_handle h, const uint16_t *A, const int8_t *B, int32_t *C, int nb,
+                      int M, int N, int K, int lda, int ldb, int ldc, int64_t strideA,
+                      int64_t strideB, int64_t strideC);
+
+/* a2 + a3, attention-shaped (vit_quant.py:70-74, 79-83):
+ * scores8[bh,i,j] = clamp8(rq(q[bh,i,:]·k[bh,j,:], dy));  scores8 is [B*H, T, lds].       */
+int ivit_attn_qk_requant(ivit_handle h, const int8_t *q, const int8_t *k, ivit_dyadic dy,
+                         int8_t *scores8, int BH, int T, int dh, int lds);
+/* ctx8[b,i,h*dh+d] = clamp8(rq(sum_j p[bh,i,j]*v[bh,j,d], dy));  p is [B*H,T,ldp] uint16,
+ * vt is [B*H,dh,ldv];  ctx8 is [B,T,H*dh] (heads merged, vit_quant.py:81).               */
+int ivit_attn_pv_requant(ivit_handle h, const uint16_t *p, const int8_t *vt, ivit_dyadic dy,
+                         int8_t *ctx8, int B, int H, int T, int dh, int ldp, int ldv);
+
+/* ---- a3  QuantAct.forward with a previous scale -> fixedpoint_mul.forward
+ * (quant_modules.py:197-206, quant_utils.py:192-253).  z int32 or float (integer-valued;
+ * the I-LayerNorm output exceeds int32), [rows, C];  dy has nch = 1 or C entries;
+ * optional identity z_id (int32, same shape) with scalar dy_id;  bits 8 -> int8 out,
+ * 16 -> int16 out, 32 -> int32 out.                                                      */
+int ivit_requant_i32(ivit_handle h, const int32_t *z, const ivit_dyadic *dy, int nch,
+                     const int32_t *z_id, const ivit_dyadic *dy_id, int bits, void *out,
+                     int64_t rows, int C);
+int ivit_requant_f32(ivit_handle h, const float *z, const ivit_dyadic *dy, int nch,
+                     const int32_t *z_id, const ivit_dyadic *dy_id, int bits, void *out,
+                     int64_t rows, int C);
+
+/* ---- a5  IntSoftmax.forward (Shiftmax)  (quant_modules.py:469-497).
+ * x int8 [rows, n] (row stride ld_in), per-tensor scale; out_bits 16 (ViT/DeiT) or 8 (Swin);
+ * integer probabilities with scale 2^-(out_bits-1), stored uint16 (16-bit results reach
+ * 32768).  fp32-faithful interior incl. torch's CPU summation order.                     */
+int ivit_shiftmax(ivit_handle h, const int8_t *x, int64_t rows, int n, int ld_in, float scale,
+                  int out_bits, uint16_t *out, int ld_out);
+
+/* ---- a6  IntGELU.forward (ShiftGELU)  (quant_modules.py:410-445).
+ * x int8 [rows, C], per-tensor scale -> out16[i] = Q*sigmoid_int (scale s*2^-7).          */
+int ivit_shiftgelu(ivit_handle h, const int8_t *x, int64_t rows, int C, float scale,
+                   int16_t *out16);
+/* a6 + a3 (layers_quant.py:146-147): ... -> clamp8(rq(Q*sigmoid_int, dy))               */
+int ivit_shiftgelu_requant(ivit_handle h, const int8_t *x, int64_t rows, int C, float scale,
+                           ivit_dyadic dy, int8_t *out8);
+
+/* ---- a7  IntLayerNorm.forward  (quant_modules.py:353-386).
+ * x int16 [rows, C] with per-tensor scale; bias_int[c] = floor(fl(fl(b/w)/sf)) and
+ * sc[c] = fl(sf*w[c]) from the host.  z[i,c] = rne(fl(fl(out*sc)/sc)) as float — the
+ * integer the following QuantAct derives (quant_utils.py:220).                           */
+int ivit_layernorm(ivit_handle h, const int16_t *x, int64_t rows, int C, float scale,
+                   const float *bias_int, const float *sc, float *z);
+/* a7 + a3 (vit_quant.py:131-132): ... -> clamp8(rq(z, dy_ch[c])).  row_stride in
+ * elements lets the final norm read only the class-token rows (vit_quant.py:271-272).    */
+int ivit_layernorm_requant(ivit_handle h, const int16_t *x, int64_t rows, int C,
+                           int64_t row_stride, float scale, const float *bias_int,
+                           const float *sc, const ivit_dyadic *dy_ch, int8_t *out8);
+
+/* ---- a8  PatchEmbed.forward: QuantConv2d(kernel=stride=P) -> QuantAct(16)
+ * (layers_quant.py:184-196, quant_modules.py:297-330), then class token + position
+ * embedding (vit_quant.py:259-265).
+ * ivit_im2col_patch: NCHW int8 image -> [B*gh*gw, Cin*P*P] rows in conv-weight order.    */
+int ivit_im2col_patch(ivit_handle h, const int8_t *img, int B, int Cin, int H, int W, int P,
+                      int8_t *rows);
+/* x16[b,0,:]  = clamp16(rq(z_cls[:], dy_x) + rq(pos[0,:], dy_pos))
+ * x16[b,1+i,:] = clamp16(rq(patch16[b,i,:], dy_x) + rq(pos[1+i,:], dy_pos))             */
+int ivit_embed_finish(ivit_handle h, const int16_t *patch16, const int32_t *z_cls,
+                      const int16_t *pos, ivit_dyadic dy_x, ivit_dyadic dy_pos, int16_t *x16,
+                      int B, int T, int D);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IVIT_H */

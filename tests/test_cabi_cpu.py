@@ -1,0 +1,70 @@
+"""CPU: the C-ABI library builds/loads and exports every symbol include/ivit.h declares;
+host-side freeze logic agrees with the oracle's independent restatement."""
+import os
+import re
+
+import numpy as np
+
+from conftest import ROOT, load_golden, golden_scales
+import ivit_amd as iv
+from ivit_amd import _lib
+
+
+def test_library_exports_header_symbols():
+    iv.build()
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "ivit.h")).read()
+    names = set(re.findall(r"\b(ivit_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), n
+    for n in _lib.SIGNATURES:
+        assert n in names, f"{n} bound in python but not declared in ivit.h"
+    assert lib.ivit_version() >= 100
+    assert lib.ivit_status_string(1) == b"invalid argument"
+
+
+def test_no_device_is_an_error_not_a_fallback():
+    import ctypes
+    import torch
+    if torch.cuda.is_available():
+        return
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    assert lib.ivit_create(ctypes.byref(h), 0, None) != 0
+
+
+def test_freeze_matches_oracle_constants():
+    from oracle import oracle as orc
+    g = load_golden("micro_vit_b2.npz")
+    cfg = iv.CONFIGS[str(g["cfg_name"])]
+    w = iv.make_vit_weights(cfg, int(g["seed"]))
+    sc = golden_scales(g)
+    c, f32 = iv.freeze.freeze_vit(cfg, w, sc)
+    o = orc.OracleViT(cfg, w, sc)
+    def dy_eq(a, d):
+        return all(a[i, 0] == d[i].m and a[i, 1] == d[i].r for i in range(len(d)))
+    assert np.array_equal(c["patch_embed.proj.w"], o.c["pe"][0])
+    assert np.array_equal(c["patch_embed.proj.b"], o.c["pe"][1])
+    assert dy_eq(c["patch_embed.proj.dy"], o.c["pe"][2])
+    assert np.array_equal(c["z_cls"], o.c["z_cls"])
+    assert np.array_equal(c["pos"].astype(np.int32), o.c["pos"])
+    for i, b in enumerate(o.blocks):
+        p = f"blocks.{i}."
+        assert np.array_equal(c[p + "attn.qkv.w"], b["qkv"][0])
+        assert np.array_equal(c[p + "attn.qkv.b"], b["qkv"][1])
+        assert dy_eq(c[p + "attn.qkv.dy"], b["qkv"][2])
+        assert dy_eq(c[p + "attn.dy_qk"], b["dy_qk"]) and dy_eq(c[p + "attn.dy_pv"], b["dy_av"])
+        assert dy_eq(c[p + "norm1.dy"], b["dy_ln1"]) and dy_eq(c[p + "norm2.dy"], b["dy_ln2"])
+        assert np.array_equal(c[p + "norm1.bias_int"], b["ln1"][0]) and np.array_equal(c[p + "norm1.sc"], b["ln1"][1])
+        assert dy_eq(c[p + "res1.dy_main"], b["dy_res1"][0]) and dy_eq(c[p + "res1.dy_res"], b["dy_res1"][1])
+        assert dy_eq(c[p + "mlp.dy_gelu"], b["dy_gelu"])
+        assert dy_eq(c[p + "res2.dy_main"], b["dy_res2"][0]) and dy_eq(c[p + "res2.dy_res"], b["dy_res2"][1])
+    assert np.array_equal(c["head.w"], o.c["head"][0]) and np.array_equal(c["head.scale"], o.c["head"][2])
+
+
+def test_dyadic_edge_cases():
+    d = iv.freeze.dyadic(np.array([1.0, -0.5, 3e-9, 1e12], np.float32), np.float32(0.37))
+    for (m, r), s in zip(d, [1.0, -0.5, 3e-9, 1e12]):
+        assert abs(m) >= 2 ** 30 and abs(m) <= 2 ** 31 and m == int(m)
+        assert np.isclose(m * r, np.float64(np.float32(s)) / np.float64(np.float32(0.37)), rtol=1e-9)

@@ -1,0 +1,202 @@
+"""GPU parity: HIP path (through the C-ABI) vs reference golden vectors and the CPU oracle.
+Bit-exact everywhere (integer outputs)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, golden_scales
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+import ivit_amd as iv  # noqa: E402
+from ivit_amd import _lib  # noqa: E402
+
+_P = ctypes.c_void_p
+
+
+@pytest.fixture(scope="module")
+def H():
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    return _lib.Handle(0, torch.cuda.current_stream().cuda_stream)
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def P(t):
+    return _P(t.data_ptr())
+
+
+def dy_dev(s_pre, s_out):
+    d = iv.freeze.dyadic(s_pre, s_out)
+    return d, dev(d)
+
+
+def dyv(d):
+    return _lib.Dyadic(float(d[0, 0]), float(d[0, 1]))
+
+
+def test_library_loaded():
+    lib = _lib.load()
+    assert lib.ivit_version() >= 100
+
+
+def test_quantize_input(H, ops_golden):
+    g = ops_golden
+    x = dev(g["quant_in/x"])
+    q = torch.empty(x.shape, dtype=torch.int8, device="cuda")
+    H.call("ivit_quantize_input_f32", P(x), float(g["quant_in/s"]), P(q), x.numel())
+    assert np.array_equal(q.cpu().numpy(), g["quant_in/out"])
+
+
+def test_shiftmax_golden(H, ops_golden):
+    g = ops_golden
+    for i in range(int(g["shiftmax/n"])):
+        x = g[f"shiftmax/{i}/x"]
+        rows, n = x.shape
+        ld = (n + 15) // 16 * 16
+        xp = np.zeros((rows, ld), np.int8)
+        xp[:, :n] = x
+        out = torch.zeros(rows, ld, dtype=torch.int16, device="cuda")
+        H.call("ivit_shiftmax", P(dev(xp)), rows, n, ld, float(g[f"shiftmax/{i}/s"]),
+               int(g[f"shiftmax/{i}/bits"]), P(out), ld)
+        got = out.cpu().numpy().view(np.uint16)[:, :n]
+        assert np.array_equal(got, g[f"shiftmax/{i}/out"]), i
+
+
+def test_shiftgelu_golden(H, ops_golden):
+    g = ops_golden
+    for i in range(int(g["gelu/n"])):
+        x = g[f"gelu/{i}/x"]
+        rows, C = x.shape
+        out = torch.empty(rows, C, dtype=torch.int16, device="cuda")
+        H.call("ivit_shiftgelu", P(dev(x)), rows, C, float(g[f"gelu/{i}/s"]), P(out))
+        assert np.array_equal(out.cpu().numpy(), g[f"gelu/{i}/out"]), i
+
+
+def test_layernorm_golden(H, ops_golden):
+    g = ops_golden
+    for i in range(int(g["ln/n"])):
+        x = g[f"ln/{i}/x"]
+        rows, C = x.shape
+        bias_int, sc = iv.freeze.layernorm_constants(g[f"ln/{i}/w"], g[f"ln/{i}/b"])
+        z = torch.empty(rows, C, dtype=torch.float32, device="cuda")
+        H.call("ivit_layernorm", P(dev(x)), rows, C, float(g[f"ln/{i}/s"]), P(dev(bias_int)), P(dev(sc)), P(z))
+        assert np.array_equal(z.cpu().numpy(), g[f"ln/{i}/z"]), i
+        d, dd = dy_dev(sc, g[f"ln/{i}/s_out"])
+        o8 = torch.empty(rows, C, dtype=torch.int8, device="cuda")
+        H.call("ivit_layernorm_requant", P(dev(x)), rows, C, C, float(g[f"ln/{i}/s"]), P(dev(bias_int)),
+               P(dev(sc)), P(dd), P(o8))
+        assert np.array_equal(o8.cpu().numpy(), g[f"ln/{i}/out8"]), i
+
+
+def test_requant_golden(H, ops_golden):
+    g = ops_golden
+    for i in range(int(g["requant/n"])):
+        z = g[f"requant/{i}/z"]
+        rows, C = z.shape
+        bits = int(g[f"requant/{i}/bits"])
+        d, dd = dy_dev(g[f"requant/{i}/s_pre"], g[f"requant/{i}/s_out"])
+        out = torch.empty(rows, C, dtype={8: torch.int8, 16: torch.int16}[bits], device="cuda")
+        if f"requant/{i}/z_id" in g.files:
+            di, ddi = dy_dev(g[f"requant/{i}/s_id"], g[f"requant/{i}/s_out"])
+            H.call("ivit_requant_f32", P(dev(z)), P(dd), d.shape[0], P(dev(g[f"requant/{i}/z_id"])), P(ddi),
+                   bits, P(out), rows, C)
+        else:
+            H.call("ivit_requant_f32", P(dev(z)), P(dd), d.shape[0], None, None, bits, P(out), rows, C)
+        assert np.array_equal(out.cpu().numpy().astype(np.int32), g[f"requant/{i}/out"]), i
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (197, 192, 192), (394, 1152, 384), (50, 1000, 384),
+                                   (1, 10, 64), (300, 96, 1536), (129, 130, 48)])
+def test_linear_i8_vs_numpy(H, M, N, K):
+    rng = np.random.default_rng(M * 7 + N)
+    x = rng.integers(-128, 128, (M, K), dtype=np.int8)
+    w = rng.integers(-128, 128, (N, K), dtype=np.int8)
+    b = rng.integers(-2 ** 20, 2 ** 20, N).astype(np.int32)
+    acc = torch.empty(M, N, dtype=torch.int32, device="cuda")
+    H.call("ivit_linear_i8", P(dev(x)), P(dev(w)), P(dev(b)), P(acc), M, N, K)
+    ref = x.astype(np.int32) @ w.astype(np.int32).T + b
+    assert np.array_equal(acc.cpu().numpy(), ref)
+
+
+def test_mfma_operand_order_asymmetric(H):
+    """A = I (padded) against an asymmetric B catches a transposed C write."""
+    K = 64
+    x = np.zeros((64, K), np.int8)
+    x[np.arange(64), np.arange(64)] = 1
+    w = (np.arange(96 * K).reshape(96, K) % 97 - 48).astype(np.int8)
+    acc = torch.empty(64, 96, dtype=torch.int32, device="cuda")
+    H.call("ivit_linear_i8", P(dev(x)), P(dev(w)), None, P(acc), 64, 96, K)
+    assert np.array_equal(acc.cpu().numpy(), w.astype(np.int32).T[:64])
+
+
+@pytest.mark.parametrize("nb,M,N,K", [(3, 197, 197, 64), (2, 17, 17, 64), (5, 49, 49, 32)])
+def test_bmm_nt_i8(H, nb, M, N, K):
+    rng = np.random.default_rng(nb + M)
+    A = rng.integers(-128, 128, (nb, M, K), dtype=np.int8)
+    B = rng.integers(-128, 128, (nb, N, K), dtype=np.int8)
+    C = torch.empty(nb, M, N, dtype=torch.int32, device="cuda")
+    H.call("ivit_bmm_nt_i8", P(dev(A)), P(dev(B)), P(C), nb, M, N, K, K, K, N, M * K, N * K, M * N)
+    ref = np.einsum("bmk,bnk->bmn", A.astype(np.int32), B.astype(np.int32))
+    assert np.array_equal(C.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("nb,M,N,K", [(3, 197, 64, 197), (2, 17, 64, 17), (2, 130, 32, 577)])
+def test_bmm_nt_u16i8_full_range(H, nb, M, N, K):
+    """16-bit probabilities incl. the extreme values 0, 32640..32768."""
+    rng = np.random.default_rng(nb * 3 + M)
+    ld = (K + 15) // 16 * 16
+    A = np.zeros((nb, M, ld), np.uint16)
+    A[:, :, :K] = rng.integers(0, 32769, (nb, M, K))
+    A[0, 0, :K] = 32768
+    A[0, 1, :K] = 32640
+    A[0, 2, :K] = 0
+    A[:, :, K:] = 12345  # garbage in the pad must be ignored
+    B = np.zeros((nb, N, ld), np.int8)
+    B[:, :, :K] = rng.integers(-128, 128, (nb, N, K))
+    B[0, 0, :K] = -128
+    B[0, 1, :K] = 127
+    B[:, :, K:] = 77
+    C = torch.empty(nb, M, N, dtype=torch.int32, device="cuda")
+    H.call("ivit_bmm_nt_u16i8", P(dev(A.view(np.int16))), P(dev(B)), P(C), nb, M, N, K, ld, ld, N,
+           M * ld, N * ld, M * N)
+    ref = np.einsum("bmk,bnk->bmn", A[:, :, :K].astype(np.int64), B[:, :, :K].astype(np.int64))
+    ref = ((ref + 2 ** 31) % 2 ** 32 - 2 ** 31).astype(np.int32)  # int32 wrap-around semantics
+    assert np.array_equal(C.cpu().numpy(), ref)
+
+
+def _engine_for(g):
+    cfg = iv.CONFIGS[str(g["cfg_name"])]
+    w = iv.make_vit_weights(cfg, int(g["seed"]))
+    from ivit_amd.engine import ViTEngine
+    return cfg, w, ViTEngine.from_float(cfg, w, golden_scales(g))
+
+
+@pytest.mark.parametrize("fname", ["micro_vit_b2.npz", "micro_vit2h_b3.npz", "deit_tiny_b1.npz",
+                                   "deit_small_b4.npz"])
+def test_vit_forward_golden_logits(fname):
+    g = load_golden(fname)
+    cfg, w, eng = _engine_for(g)
+    imgs = iv.make_images_int8(cfg, int(g["batch"]), int(g["images_seed"]))
+    logits = eng.forward(dev(imgs)).cpu().numpy()
+    assert np.array_equal(logits, g["logits_int"])
+    assert np.array_equal(eng.head_scale(), g["logits_scale"])
+
+
+def test_vit_forward_vs_oracle_residual_stream():
+    """final residual stream + logits vs the CPU oracle on a fresh image seed."""
+    from oracle import oracle as orc
+    g = load_golden("deit_tiny_b1.npz")
+    cfg, w, eng = _engine_for(g)
+    imgs = iv.make_images_int8(cfg, 3, seed=99)
+    o = orc.OracleViT(cfg, w, golden_scales(g))
+    cap = {}
+    ref_logits, _ = o.forward(imgs, cap)
+    logits = eng.forward(dev(imgs)).cpu().numpy()
+    x_last = eng.last_x.cpu().numpy().reshape(3, cfg.num_tokens, cfg.embed_dim)
+    assert np.array_equal(x_last, cap[f"blocks.{cfg.depth - 1}.qact4"].astype(np.int16))
+    assert np.array_equal(logits, ref_logits)
