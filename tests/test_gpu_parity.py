@@ -22,8 +22,17 @@ def H():
     return _lib.Handle(0, torch.cuda.current_stream().cuda_stream)
 
 
+_KEEP = []
+
+
 def dev(a):
-    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    """host -> device; the tensor is kept alive (raw pointers are handed to the C-ABI)."""
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    _KEEP.append(t)
+    if len(_KEEP) > 64:
+        torch.cuda.synchronize()
+        del _KEEP[:32]
+    return t
 
 
 def P(t):
