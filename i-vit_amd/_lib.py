@@ -56,11 +56,14 @@ SIGNATURES = {
     "ivit_bmm_nt_u16i8": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _L, _L],
     "ivit_attn_qk_requant": [_P, _P, _P, Dyadic, _P, _I, _I, _I, _I],
     "ivit_attn_pv_requant": [_P, _P, _P, Dyadic, _P, _I, _I, _I, _I, _I, _I],
+    "ivit_attention_fused": [_P, _P, _P, _P, Dyadic, _F, Dyadic, _P, _I, _I, _I, _I, _I],
     "ivit_requant_i32": [_P, _P, _P, _I, _P, _P, _I, _P, _L, _I],
     "ivit_requant_f32": [_P, _P, _P, _I, _P, _P, _I, _P, _L, _I],
     "ivit_shiftmax": [_P, _P, _L, _I, _I, _F, _I, _P, _I],
     "ivit_shiftgelu": [_P, _P, _L, _I, _F, _P],
     "ivit_shiftgelu_requant": [_P, _P, _L, _I, _F, Dyadic, _P],
+    "ivit_shiftgelu_build_table": [_P, _F, Dyadic, _P],
+    "ivit_shiftgelu_requant_lut": [_P, _P, _L, _I, _P, _P],
     "ivit_layernorm": [_P, _P, _L, _I, _F, _P, _P, _P],
     "ivit_layernorm_requant": [_P, _P, _L, _I, _L, _F, _P, _P, _P, _P],
     "ivit_im2col_patch": [_P, _P, _I, _I, _I, _I, _I, _P],

@@ -1,0 +1,294 @@
+// ivit_attention.h — fused integer attention for gfx950 (reference
+// models/vit_quant.py:70-83: matmul_1 -> *scale -> qact_attn1 -> IntSoftmax(16) ->
+// matmul_2 -> qact2), one workgroup per (image, head).
+//
+// Layout trick: S^T = K · Q^T is computed with v_mfma_i32_16x16x64_i8 (A = 16 keys x dh,
+// B = 16 queries), so in the accumulator layout (col = lane&15 = query, row = 4*(lane>>4)
+// + reg = key) the whole score row of one query sits in the registers of 4 lanes:
+//   * row max and the torch-ordered row sum of Shiftmax are (almost) lane-local,
+//   * the 16-bit probabilities, split into two int8 planes, ARE the A operand of the
+//     P·V MFMA (K = 64 keys = 4 consecutive 16-key tiles), no cross-lane movement.
+// Scores and probabilities never touch LDS or HBM.  K and V^T of the head are staged in
+// LDS once (XOR-swizzled / stride-skewed so every ds_read_b128 is conflict-free); V^T is
+// stored with the key order permuted to match the P fragment's key order.
+//
+// 16-bit P (0..32768): P - 16384 = 256*hi + lo, hi in [-64,64], lo in [-128,127];
+// out = lo·V + 256*(hi·V) + 16384*colsum(V), all exact in int32.
+#pragma once
+#include "ivit_device.h"
+
+struct AttnArgs {
+    const int8_t *q, *k, *vt;  // q,k: [B*H, T, dh=64]; vt: [B*H, 64, ldv]
+    int8_t *ctx;               // [B, T, H*64]
+    int T, H, ldv;
+    float s_softmax;           // scale of the int8 scores (qact_attn1)
+    ivit_dyadic dy_qk, dy_pv;
+};
+
+#define ATT_WAVES 7
+#define ATT_DH 64
+
+__device__ __forceinline__ int att_kswz(int row, int g) {   // 16-byte chunk position in a K row
+    return g ^ ((0x78 >> (2 * ((row >> 2) & 3))) & 3);
+}
+
+template <int NB>  // key blocks of 64 (T <= 64*NB)
+struct AttCfg {
+    static constexpr int TK = NB * 64;
+    static constexpr int NT = NB * 4;  // 16-key tiles
+    // sV row stride in 16-byte slots: smallest >= TK/16 that is == 2 (mod 16)
+    static constexpr int VS_SLOTS = ((TK / 16 + 13) / 16) * 16 + 2;
+    static constexpr int VS = VS_SLOTS * 16;
+    static constexpr int SK_BYTES = TK * 64;
+    static constexpr int SV_BYTES = 64 * VS;
+    static constexpr int SO_BYTES = ATT_WAVES * 1024;
+    static constexpr int SMEM = SK_BYTES + SV_BYTES + SO_BYTES + 256;
+};
+
+template <int NB>
+__global__ __launch_bounds__(ATT_WAVES * 64) void attn_fused_kernel(AttnArgs p) {
+    using C = AttCfg<NB>;
+    extern __shared__ __attribute__((aligned(16))) char dsmem[];
+    char *sK = dsmem;
+    char *sV = dsmem + C::SK_BYTES;
+    char *sO = sV + C::SV_BYTES;
+    int *sCol = reinterpret_cast<int *>(sO + C::SO_BYTES);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
+    const int T = p.T;
+    const int8_t *qg = p.q + (long long)bh * T * 64;
+    const int8_t *kg = p.k + (long long)bh * T * 64;
+    const int8_t *vg = p.vt + (long long)bh * 64 * p.ldv;
+
+    // ---- stage K (rows >= T zero) and V^T (keys >= T zero, permuted) into LDS
+    for (int c = tid; c < C::TK * 4; c += ATT_WAVES * 64) {
+        int row = c >> 2, g = c & 3;
+        v4i v = {0, 0, 0, 0};
+        if (row < T) v = *reinterpret_cast<const v4i *>(kg + row * 64 + g * 16);
+        *reinterpret_cast<v4i *>(sK + row * 64 + att_kswz(row, g) * 16) = v;
+    }
+    for (int c = tid; c < 64 * C::NT; c += ATT_WAVES * 64) {
+        int d = c / C::NT, i = c - d * C::NT;   // i: 16-key chunk index
+        int t0 = i * 16;
+        v4i v = {0, 0, 0, 0};
+        if (t0 < T) {
+            v = *reinterpret_cast<const v4i *>(vg + (long long)d * p.ldv + t0);
+            if (t0 + 16 > T) {
+                int valid = T - t0;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    int nb = valid - w * 4;
+                    unsigned m = nb >= 4 ? 0xffffffffu : (nb <= 0 ? 0u : ((1u << (nb * 8)) - 1u));
+                    v[w] &= (int)m;
+                }
+            }
+        }
+        int kb = i >> 2, jj = i & 3;
+        char *dst = sV + d * C::VS + kb * 64 + jj * 4;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<int *>(dst + g * 16) = v[g];
+    }
+    __syncthreads();
+    if (tid < 64) {  // column sums of V (per d) over all keys
+        int s = 0;
+        const int *row = reinterpret_cast<const int *>(sV + tid * C::VS);
+        for (int w = 0; w < C::TK / 4; ++w) s = __builtin_amdgcn_sdot4(row[w], 0x01010101, s, false);
+        sCol[tid] = s;
+    }
+    __syncthreads();
+
+    const int qi = lane & 15, g = lane >> 4;
+    const float s = p.s_softmax;
+    const float x0 = floorf(-1.0f / s);
+    const float nx0 = 15.0f * x0;
+    const int ntile = (T + 15) >> 4;       // live 16-key tiles
+    const int nqt = (T + 15) >> 4;         // query tiles
+    const int nvec = T >> 3, size = nvec >> 2;
+
+    for (int qt = wave; qt < nqt; qt += ATT_WAVES) {
+        const int q0 = qt * 16;
+        // ---- Q fragment (B operand): query qi, dh bytes [16g, 16g+16)
+        v4i qf = {0, 0, 0, 0};
+        if (q0 + qi < T) qf = *reinterpret_cast<const v4i *>(qg + (q0 + qi) * 64 + g * 16);
+
+        // ---- S^T tiles -> requant -> float(Q); running integer max
+        float f[C::NT][4];
+        int qmax = -128;
+#pragma unroll
+        for (int j = 0; j < C::NT; ++j) {
+            if (j < ntile) {
+                int row = j * 16 + qi;
+                v4i kf = *reinterpret_cast<const v4i *>(sK + row * 64 + att_kswz(row, g) * 16);
+                v4i acc = {0, 0, 0, 0};
+                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(kf, qf, acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int t = j * 16 + g * 4 + r;
+                    int v = clamp_b<8>(rq_f64((double)acc[r], p.dy_qk.m, p.dy_qk.r));
+                    f[j][r] = (float)v;
+                    if (t < T) qmax = max(qmax, v);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) f[j][r] = 0.f;
+            }
+        }
+        qmax = max(qmax, __shfl_xor(qmax, 16));
+        qmax = max(qmax, __shfl_xor(qmax, 32));
+        const float mx = requotient((float)qmax, s);
+
+        // ---- shift-exp; keys >= T contribute exactly 0
+#pragma unroll
+        for (int j = 0; j < C::NT; ++j) {
+            if (j < ntile) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int t = j * 16 + g * 4 + r;
+                    float e = shift_exp(requotient(f[j][r], s) - mx, x0, nx0, 15);
+                    f[j][r] = t < T ? e : 0.f;
+                }
+            }
+        }
+
+        // ---- row sum in torch's CPU order (ivit_device.h torch_order_sum32):
+        // element t -> accumulator a = t & 31 = 16*(j&1) + 4*g + r, step = j >> 1
+        float A0[2][4], A1[2][4], A2[2][4], A3[2][4];
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { A0[pp][r] = 0.f; A1[pp][r] = 0.f; A2[pp][r] = 0.f; A3[pp][r] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < C::NT / 2; ++i) {
+            if (i < size) {
+                const bool in_blocks = (i < (size & ~15));   // inside a full 16-step level block
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) A0[pp][r] += f[2 * i + pp][r];
+                if (in_blocks && ((i + 1) & 15) == 0) {
+                    const int ii = i + 1;
+#pragma unroll
+                    for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            A1[pp][r] += A0[pp][r]; A0[pp][r] = 0.f;
+                            if ((ii & 0xF0) == 0) {
+                                A2[pp][r] += A1[pp][r]; A1[pp][r] = 0.f;
+                                if ((ii & 0xF00) == 0) { A3[pp][r] += A2[pp][r]; A2[pp][r] = 0.f; }
+                            }
+                        }
+                }
+            }
+        }
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { A0[pp][r] += A1[pp][r]; A0[pp][r] += A2[pp][r]; A0[pp][r] += A3[pp][r]; }
+        // leftover whole 8-vectors (nvec % 4) go to accumulators a = 0..7 (lanes g = 0,1)
+        for (int v = size * 4; v < nvec; ++v) {
+            const int jv = v >> 1, odd = v & 1;
+            float val[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < C::NT; ++j)
+                if (j == jv) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) val[r] = f[j][r];
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float o = __shfl(val[r], (lane + 32 * odd) & 63);
+                if (g < 2) A0[0][r] += o;
+            }
+        }
+        // p[l] = ((acc[l] + acc[8+l]) + acc[16+l]) + acc[24+l];  a = 16*pp + 4*g + r
+        float pl[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float o0 = __shfl_xor(A0[0][r], 32), o1 = __shfl_xor(A0[1][r], 32);
+            pl[r] = ((A0[0][r] + o0) + A0[1][r]) + o1;   // valid on lanes g = 0 (l=r) and g = 1 (l=4+r)
+        }
+        float fin = 0.f;
+        for (int t = nvec * 8; t < T; ++t) {   // scalar tail, sequential
+            const int jt = t >> 4, gt = (t >> 2) & 3, rt = t & 3;
+            float val = 0.f;
+#pragma unroll
+            for (int j = 0; j < C::NT; ++j)
+                if (j == jt) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (r == rt) val = f[j][r];
+                }
+            fin += __shfl(val, (gt << 4) | qi);
+        }
+        if (nvec > 0) {
+#pragma unroll
+            for (int l = 0; l < 8; ++l) fin += __shfl(pl[l & 3], ((l >> 2) << 4) | qi);
+        }
+        const float F = recip_factor(fin);
+
+        // ---- probabilities -> (hi, lo) int8 planes, packed as P·V A fragments
+        v4i plo[NB], phi[NB];
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j = kb * 4 + jj;
+                unsigned wl = 0, wh = 0;
+                if (j < ntile) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        int P = (int)floorf((f[j][r] * F) * 1.52587890625e-05f);  // / 2**16
+                        int a = P - 16384;
+                        int l8 = (int)(int8_t)(a & 0xff);
+                        int h8 = (a - l8) >> 8;
+                        wl |= (unsigned)(l8 & 0xff) << (8 * r);
+                        wh |= (unsigned)(h8 & 0xff) << (8 * r);
+                    }
+                } else {
+                    wh = 0xC0C0C0C0u;  // P = 0 -> a = -16384 -> hi = -64, lo = 0 (V is 0 there)
+                }
+                plo[kb][jj] = (int)wl;
+                phi[kb][jj] = (int)wh;
+            }
+
+        // ---- P·V : out[query 4g+r][d = 16*dt + qi]
+        v4i oL[4], oH[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { oL[dt] = v4i{0, 0, 0, 0}; oH[dt] = v4i{0, 0, 0, 0}; }
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) {
+            if (kb * 64 < T) {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    v4i vf = *reinterpret_cast<const v4i *>(sV + (dt * 16 + qi) * C::VS + kb * 64 + g * 16);
+                    oL[dt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(plo[kb], vf, oL[dt], 0, 0, 0);
+                    oH[dt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(phi[kb], vf, oH[dt], 0, 0, 0);
+                }
+            }
+        }
+        // ---- epilogue: exact recombination, requant, stage [16 q][64 d] and store rows
+        char *so = sO + wave * 1024;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const int cs = sCol[dt * 16 + qi];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int v = (int)((unsigned)oL[dt][r] + ((unsigned)oH[dt][r] << 8) + ((unsigned)cs << 14));
+                int o = clamp_b<8>(rq_f64((double)v, p.dy_pv.m, p.dy_pv.r));
+                so[(g * 4 + r) * 64 + dt * 16 + qi] = (char)o;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        {
+            const int row = lane >> 2, ch = lane & 3;
+            if (q0 + row < T) {
+                v4i v = *reinterpret_cast<const v4i *>(so + row * 64 + ch * 16);
+                *reinterpret_cast<v4i *>(p.ctx + ((long long)b * T + q0 + row) * (p.H * 64) + h * 64 + ch * 16) = v;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+}

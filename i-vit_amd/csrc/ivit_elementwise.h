@@ -302,3 +302,65 @@ __global__ __launch_bounds__(256) void embed_finish_kernel(const int16_t *__rest
         x16[i] = (int16_t)clamp_b<16>(o);
     }
 }
+
+// ---------------------------------------------------------------------------
+// ShiftGELU(+requant) as a table: for a frozen layer (scale s, dyadic dy) the int8
+// output is a pure function of (Q, row max), so tab[(qmax+128)*256 + (Q+128)] is
+// built ONCE at freeze time by the same faithful device code (64 KB per layer) and
+// the per-token work becomes: row max -> copy one 256-byte table row to LDS ->
+// byte gathers.  Bit-identical to shiftgelu_kernel<true> by construction
+// (tests/test_gpu_parity.py::test_shiftgelu_lut_equals_direct).
+__global__ __launch_bounds__(256) void shiftgelu_table_kernel(float s, ivit_dyadic dy, int8_t *__restrict__ tab) {
+    const int qmax = (int)blockIdx.x - 128, q = (int)threadIdx.x - 128;
+    const float mx = requotient((float)qmax, s);
+    const float ssig = s * 1.702f;
+    const float x0 = floorf(-1.0f / ssig);
+    const float nx0 = 23.0f * x0;
+    const float emax = shift_exp(-mx, x0, nx0, 23);
+    float p = requotient((float)q, s);
+    float e = shift_exp(p - mx, x0, nx0, 23);
+    float F = recip_factor(e + emax);
+    float sig = floorf((e * F) * 5.9604644775390625e-08f);
+    int prod = (int)rintf(p * sig);
+    tab[blockIdx.x * 256 + threadIdx.x] = (int8_t)clamp_b<8>(rq_f64((double)prod, dy.m, dy.r));
+}
+
+__global__ __launch_bounds__(256) void shiftgelu_lut_kernel(const int8_t *__restrict__ x, long long rows, int C,
+                                                            const int8_t *__restrict__ tab,
+                                                            int8_t *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) unsigned char lut[4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long row = (long long)blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    const int8_t *xp = x + row * C;
+    const int nch = C >> 4;
+    int qmax = -128;
+    for (int c = lane; c < nch; c += 64) {
+        v4i v = *reinterpret_cast<const v4i *>(xp + c * 16);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            // signed byte max of 4 packed int8: compare as sign-extended fields
+            int w = v[d];
+            qmax = max(qmax, max(max((w << 24) >> 24, (w << 16) >> 24), max((w << 8) >> 24, w >> 24)));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) qmax = max(qmax, __shfl_xor(qmax, o));
+    reinterpret_cast<unsigned *>(lut[wave])[lane] =
+        reinterpret_cast<const unsigned *>(tab + (qmax + 128) * 256)[lane];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const unsigned char *L = lut[wave];
+    for (int c = lane; c < nch; c += 64) {
+        v4i v = *reinterpret_cast<const v4i *>(xp + c * 16);
+        v4i o;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            unsigned w = (unsigned)v[d] ^ 0x80808080u;   // Q + 128 per byte
+            unsigned r = (unsigned)L[w & 0xff] | ((unsigned)L[(w >> 8) & 0xff] << 8) |
+                         ((unsigned)L[(w >> 16) & 0xff] << 16) | ((unsigned)L[w >> 24] << 24);
+            o[d] = (int)r;
+        }
+        *reinterpret_cast<v4i *>(out + row * C + c * 16) = o;
+    }
+}

@@ -6,6 +6,7 @@
 #include "ivit_device.h"
 #include "ivit_elementwise.h"
 #include "ivit_gemm.h"
+#include "ivit_attention.h"
 
 struct ivit_ctx {
     int device;
@@ -207,6 +208,38 @@ int ivit_attn_pv_requant(ivit_handle h, const uint16_t *p, const int8_t *vt, ivi
 
 }  // extern "C"
 
+template <int NB>
+static int launch_attn(ivit_handle h, const AttnArgs &a, int BH) {
+    const size_t lds = AttCfg<NB>::SMEM;
+    if (lds > 65536) {
+        hipError_t e = hipFuncSetAttribute((const void *)attn_fused_kernel<NB>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { snprintf(h->err, sizeof(h->err), "attn attr: %s", hipGetErrorString(e)); return IVIT_ERR_HIP; }
+    }
+    attn_fused_kernel<NB><<<BH, ATT_WAVES * 64, lds, h->stream>>>(a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(h->err, sizeof(h->err), "attn launch: %s", hipGetErrorString(e)); return IVIT_ERR_HIP; }
+    return IVIT_OK;
+}
+
+extern "C" int ivit_attention_fused(ivit_handle h, const int8_t *q, const int8_t *k, const int8_t *vt,
+                                    ivit_dyadic dy_qk, float s_softmax, ivit_dyadic dy_pv, int8_t *ctx8, int B,
+                                    int H, int T, int dh, int ldv) {
+    CHECK_H(h);
+    REQUIRE(h, q && k && vt && ctx8 && B > 0 && H > 0 && T > 0 && s_softmax > 0.f, "bad arguments");
+    REQUIRE(h, (ldv % 16) == 0 && ldv >= T, "ldv must be a multiple of 16 and >= T");
+    if (dh != 64 || T > 640) {
+        snprintf(h->err, sizeof(h->err), "ivit_attention_fused: built for dh == 64, T <= 640");
+        return IVIT_ERR_UNSUPPORTED;
+    }
+    AttnArgs a;
+    a.q = q; a.k = k; a.vt = vt; a.ctx = ctx8; a.T = T; a.H = H; a.ldv = ldv;
+    a.s_softmax = s_softmax; a.dy_qk = dy_qk; a.dy_pv = dy_pv;
+    if (T <= 64) return launch_attn<1>(h, a, B * H);
+    if (T <= 256) return launch_attn<4>(h, a, B * H);
+    return launch_attn<10>(h, a, B * H);
+}
+
 // ---------------------------------------------------------------- requant
 template <typename ZT>
 static int requant_any(ivit_handle h, const ZT *z, const ivit_dyadic *dy, int nch, const int32_t *z_id,
@@ -284,6 +317,24 @@ int ivit_shiftgelu_requant(ivit_handle h, const int8_t *x, int64_t rows, int C, 
     REQUIRE(h, x && out8 && rows > 0 && C > 0 && scale > 0.f, "bad arguments");
     REQUIRE(h, (C % 16) == 0, "C must be a multiple of 16");
     shiftgelu_kernel<true><<<(unsigned)((rows + 3) / 4), 256, 0, h->stream>>>(x, rows, C, scale, dy, out8);
+    LAUNCH_CHECK(h);
+    return IVIT_OK;
+}
+
+int ivit_shiftgelu_build_table(ivit_handle h, float scale, ivit_dyadic dy, int8_t *table) {
+    CHECK_H(h);
+    REQUIRE(h, table && scale > 0.f, "bad arguments");
+    shiftgelu_table_kernel<<<256, 256, 0, h->stream>>>(scale, dy, table);
+    LAUNCH_CHECK(h);
+    return IVIT_OK;
+}
+
+int ivit_shiftgelu_requant_lut(ivit_handle h, const int8_t *x, int64_t rows, int C, const int8_t *table,
+                               int8_t *out8) {
+    CHECK_H(h);
+    REQUIRE(h, x && out8 && table && rows > 0 && C > 0, "bad arguments");
+    REQUIRE(h, (C % 16) == 0, "C must be a multiple of 16");
+    shiftgelu_lut_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, h->stream>>>(x, rows, C, table, out8);
     LAUNCH_CHECK(h);
     return IVIT_OK;
 }

@@ -69,6 +69,13 @@ class ViTEngine:
                 self.host[k] = hb[o:o + 16].view(np.float64).reshape(1, 2).copy()
         self.h = _lib.Handle(self.device.index or 0, torch.cuda.current_stream(self.device).cuda_stream)
         self._ws = {}
+        self.fused_attention = (cfg.head_dim == 64 and cfg.num_tokens <= 640)
+        # per-layer ShiftGELU(+requant) tables, built on-device by the faithful kernel code
+        self.gelu_tab = torch.empty(cfg.depth, 65536, dtype=torch.int8, device=self.device)
+        for i in range(cfg.depth):
+            p = f"blocks.{i}."
+            self.h.call("ivit_shiftgelu_build_table", self.f32[p + "mlp.s_gelu"], _dy(self.host[p + "mlp.dy_gelu"]),
+                        _P(self.gelu_tab[i].data_ptr()))
 
     @classmethod
     def from_float(cls, cfg, weights, scales, device="cuda:0"):
@@ -136,11 +143,15 @@ class ViTEngine:
                  self.ptr(p + "norm1.sc"), self.ptr(p + "norm1.dy"), P(ws["a8"]))
             call("ivit_linear_i8_qkv", P(ws["a8"]), self.ptr(p + "attn.qkv.w"), self.ptr(p + "attn.qkv.b"),
                  self.ptr(p + "attn.qkv.dy"), P(ws["q"]), P(ws["k"]), P(ws["vt"]), B, T, H, dh, ld)
-            call("ivit_attn_qk_requant", P(ws["q"]), P(ws["k"]), _dy(hc[p + "attn.dy_qk"]), P(ws["s8"]),
-                 B * H, T, dh, ld)
-            call("ivit_shiftmax", P(ws["s8"]), B * H * T, T, ld, f32[p + "attn.s_softmax"], 16, P(ws["p16"]), ld)
-            call("ivit_attn_pv_requant", P(ws["p16"]), P(ws["vt"]), _dy(hc[p + "attn.dy_pv"]), P(ws["ctx8"]),
-                 B, H, T, dh, ld, ld)
+            if self.fused_attention:
+                call("ivit_attention_fused", P(ws["q"]), P(ws["k"]), P(ws["vt"]), _dy(hc[p + "attn.dy_qk"]),
+                     f32[p + "attn.s_softmax"], _dy(hc[p + "attn.dy_pv"]), P(ws["ctx8"]), B, H, T, dh, ld)
+            else:
+                call("ivit_attn_qk_requant", P(ws["q"]), P(ws["k"]), _dy(hc[p + "attn.dy_qk"]), P(ws["s8"]),
+                     B * H, T, dh, ld)
+                call("ivit_shiftmax", P(ws["s8"]), B * H * T, T, ld, f32[p + "attn.s_softmax"], 16, P(ws["p16"]), ld)
+                call("ivit_attn_pv_requant", P(ws["p16"]), P(ws["vt"]), _dy(hc[p + "attn.dy_pv"]), P(ws["ctx8"]),
+                     B, H, T, dh, ld, ld)
             call("ivit_linear_i8_requant_residual", P(ws["ctx8"]), self.ptr(p + "attn.proj.w"),
                  self.ptr(p + "attn.proj.b"), self.ptr(p + "attn.proj.dy"), _dy(hc[p + "res1.dy_main"]),
                  _dy(hc[p + "res1.dy_res"]), P(x), P(y), M, D, D)
@@ -149,8 +160,7 @@ class ViTEngine:
                  self.ptr(p + "norm2.sc"), self.ptr(p + "norm2.dy"), P(ws["a8"]))
             call("ivit_linear_i8_requant", P(ws["a8"]), self.ptr(p + "mlp.fc1.w"), self.ptr(p + "mlp.fc1.b"),
                  self.ptr(p + "mlp.fc1.dy"), 8, P(ws["h8"]), M, Hd, D)
-            call("ivit_shiftgelu_requant", P(ws["h8"]), M, Hd, f32[p + "mlp.s_gelu"], _dy(hc[p + "mlp.dy_gelu"]),
-                 P(ws["g8"]))
+            call("ivit_shiftgelu_requant_lut", P(ws["h8"]), M, Hd, _P(self.gelu_tab[i].data_ptr()), P(ws["g8"]))
             call("ivit_linear_i8_requant_residual", P(ws["g8"]), self.ptr(p + "mlp.fc2.w"),
                  self.ptr(p + "mlp.fc2.b"), self.ptr(p + "mlp.fc2.dy"), _dy(hc[p + "res2.dy_main"]),
                  _dy(hc[p + "res2.dy_res"]), P(x), P(y), M, D, Hd)

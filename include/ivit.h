@@ -107,6 +107,15 @@ int ivit_attn_qk_requant(ivit_handle h, const int8_t *q, const int8_t *k, ivit_d
 int ivit_attn_pv_requant(ivit_handle h, const uint16_t *p, const int8_t *vt, ivit_dyadic dy,
                          int8_t *ctx8, int B, int H, int T, int dh, int ldp, int ldv);
 
+/* a10 core, fused (vit_quant.py:70-83): matmul_1 -> *scale -> qact_attn1 -> IntSoftmax(16)
+ * -> matmul_2 -> qact2 in ONE kernel per (image, head); scores and probabilities stay in
+ * registers.  Bit-identical to ivit_attn_qk_requant + ivit_shiftmax + ivit_attn_pv_requant.
+ * q,k [B*H,T,dh], vt [B*H,dh,ldv] (as written by ivit_linear_i8_qkv), ctx8 [B,T,H*dh].
+ * Built for dh == 64 and T <= 640 (DeiT/ViT at 224 and 384); else IVIT_ERR_UNSUPPORTED.   */
+int ivit_attention_fused(ivit_handle h, const int8_t *q, const int8_t *k, const int8_t *vt,
+                         ivit_dyadic dy_qk, float s_softmax, ivit_dyadic dy_pv, int8_t *ctx8,
+                         int B, int H, int T, int dh, int ldv);
+
 /* ---- a3  QuantAct.forward with a previous scale -> fixedpoint_mul.forward
  * (quant_modules.py:197-206, quant_utils.py:192-253).  z int32 or float (integer-valued;
  * the I-LayerNorm output exceeds int32), [rows, C];  dy has nch = 1 or C entries;
@@ -133,6 +142,14 @@ int ivit_shiftgelu(ivit_handle h, const int8_t *x, int64_t rows, int C, float sc
 /* a6 + a3 (layers_quant.py:146-147): ... -> clamp8(rq(Q*sigmoid_int, dy))               */
 int ivit_shiftgelu_requant(ivit_handle h, const int8_t *x, int64_t rows, int C, float scale,
                            ivit_dyadic dy, int8_t *out8);
+
+/* Same function as ivit_shiftgelu_requant, table form.  For a frozen layer the int8 result
+ * depends only on (Q, row max): ivit_shiftgelu_build_table fills table[(qmax+128)*256 +
+ * (Q+128)] (65536 bytes) once with the same device arithmetic; the per-token call is then
+ * a row max plus byte gathers (HBM-bound instead of VALU-bound).                          */
+int ivit_shiftgelu_build_table(ivit_handle h, float scale, ivit_dyadic dy, int8_t *table);
+int ivit_shiftgelu_requant_lut(ivit_handle h, const int8_t *x, int64_t rows, int C,
+                               const int8_t *table, int8_t *out8);
 
 /* ---- a7  IntLayerNorm.forward  (quant_modules.py:353-386).
  * x int16 [rows, C] with per-tensor scale; bias_int[c] = floor(fl(fl(b/w)/sf)) and

@@ -86,6 +86,27 @@ def test_shiftgelu_golden(H, ops_golden):
         assert np.array_equal(out.cpu().numpy(), g[f"gelu/{i}/out"]), i
 
 
+def test_shiftgelu_lut_equals_direct(H, ops_golden):
+    """table form == direct fp32-faithful form == reference golden (after requant)."""
+    g = ops_golden
+    from oracle import oracle as orc
+    for i in range(int(g["gelu/n"])):
+        x = g[f"gelu/{i}/x"]
+        rows, C = x.shape
+        s = float(g[f"gelu/{i}/s"])
+        d = iv.freeze.dyadic(np.float32(np.float32(s) * np.float32(2.0 ** -7)), np.float32(0.0143))
+        xd = dev(x)
+        direct = torch.empty(rows, C, dtype=torch.int8, device="cuda")
+        H.call("ivit_shiftgelu_requant", P(xd), rows, C, s, dyv(d), P(direct))
+        tab = torch.empty(65536, dtype=torch.int8, device="cuda")
+        H.call("ivit_shiftgelu_build_table", s, dyv(d), P(tab))
+        lut = torch.empty(rows, C, dtype=torch.int8, device="cuda")
+        H.call("ivit_shiftgelu_requant_lut", P(xd), rows, C, P(tab), P(lut))
+        ref = orc.requant(g[f"gelu/{i}/out"].astype(np.int32), orc.dyadic(np.float32(np.float32(s) * np.float32(2.0 ** -7)), np.float32(0.0143)), 8)
+        assert np.array_equal(direct.cpu().numpy().astype(np.int32), ref), i
+        assert np.array_equal(lut.cpu().numpy(), direct.cpu().numpy()), i
+
+
 def test_layernorm_golden(H, ops_golden):
     g = ops_golden
     for i in range(int(g["ln/n"])):
@@ -176,6 +197,38 @@ def test_bmm_nt_u16i8_full_range(H, nb, M, N, K):
     ref = np.einsum("bmk,bnk->bmn", A[:, :, :K].astype(np.int64), B[:, :, :K].astype(np.int64))
     ref = ((ref + 2 ** 31) % 2 ** 32 - 2 ** 31).astype(np.int32)  # int32 wrap-around semantics
     assert np.array_equal(C.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("B,Hh,T", [(2, 3, 197), (1, 2, 17), (3, 1, 64), (1, 2, 577), (2, 2, 200), (1, 1, 250)])
+def test_fused_attention_equals_unfused_chain(H, B, Hh, T):
+    """fused kernel == qk_requant + shiftmax + pv_requant (themselves golden-pinned)."""
+    rng = np.random.default_rng(T * 13 + B)
+    dh, ld = 64, (T + 15) // 16 * 16
+    q = rng.integers(-128, 128, (B * Hh, T, dh), dtype=np.int8)
+    k = rng.integers(-128, 128, (B * Hh, T, dh), dtype=np.int8)
+    k = (k.astype(np.int32) // 2).astype(np.int8)
+    if T > 20:
+        k[:, 5] = q[:, 7] // 2 + 60  # peaky rows
+    vt = np.zeros((B * Hh, dh, ld), np.int8)
+    vt[:, :, :T] = rng.integers(-128, 128, (B * Hh, dh, T))
+    s1 = np.float32(0.034)
+    zmax = np.abs(np.einsum("bik,bjk->bij", q.astype(np.int32), k.astype(np.int32))).max()
+    s_qk = np.float32(np.float32(s1 * s1) * np.float32(0.125))
+    s_att = np.float32(zmax * s_qk / 127.0)
+    d_qk = iv.freeze.dyadic(s_qk, s_att)
+    d_pv = iv.freeze.dyadic(np.float32(np.float32(2.0 ** -15) * s1), np.float32(0.017))
+    qd, kd, vd = dev(q), dev(k), dev(vt)
+    s8 = torch.zeros(B * Hh, T, ld, dtype=torch.int8, device="cuda")
+    p16 = torch.zeros(B * Hh, T, ld, dtype=torch.int16, device="cuda")
+    c_ref = torch.zeros(B, T, Hh * dh, dtype=torch.int8, device="cuda")
+    c_fus = torch.zeros(B, T, Hh * dh, dtype=torch.int8, device="cuda")
+    H.call("ivit_attn_qk_requant", P(qd), P(kd), dyv(d_qk), P(s8), B * Hh, T, dh, ld)
+    H.call("ivit_shiftmax", P(s8), B * Hh * T, T, ld, float(s_att), 16, P(p16), ld)
+    H.call("ivit_attn_pv_requant", P(p16), P(vd), dyv(d_pv), P(c_ref), B, Hh, T, dh, ld, ld)
+    H.call("ivit_attention_fused", P(qd), P(kd), P(vd), dyv(d_qk), float(s_att), dyv(d_pv), P(c_fus), B, Hh, T, dh, ld)
+    a, bb = c_ref.cpu().numpy(), c_fus.cpu().numpy()
+    assert np.abs(a.astype(np.int32)).max() > 20, "degenerate test data"
+    assert np.array_equal(a, bb), f"{(a != bb).sum()} / {a.size} differ"
 
 
 def _engine_for(g):
