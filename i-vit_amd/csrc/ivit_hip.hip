@@ -7,6 +7,7 @@
 #include "ivit_elementwise.h"
 #include "ivit_gemm.h"
 #include "ivit_attention.h"
+#include "ivit_gemm2.h"
 
 struct ivit_ctx {
     int device;
@@ -97,6 +98,21 @@ static int launch_gemm(ivit_handle h, GemmArgs &a, int nb) {
     return IVIT_OK;
 }
 
+// production path for the QuantLinear GEMMs: K % 64 == 0, int8 A, requant epilogues
+template <int EPI>
+static int launch_gemm2(ivit_handle h, GemmArgs &a) {
+    const int tm = (a.M + G2_BM - 1) / G2_BM;
+    a.tiles_n = (a.N + G2_BN - 1) / G2_BN;
+    gemm_glds_kernel<EPI><<<dim3((unsigned)(tm * a.tiles_n)), 512, 0, h->stream>>>(a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(h->err, sizeof(h->err), "gemm2 launch: %s", hipGetErrorString(e));
+        return IVIT_ERR_HIP;
+    }
+    return IVIT_OK;
+}
+static inline bool use_gemm2(const GemmArgs &a) { return (a.K % G2_BK) == 0 && (a.lda % 16) == 0 && (a.ldb % 16) == 0; }
+
 static GemmArgs linear_args(const int8_t *x, const int8_t *w, const int32_t *bias, int M, int N, int K) {
     GemmArgs a;
     memset(&a, 0, sizeof(a));
@@ -126,6 +142,7 @@ int ivit_linear_i8_requant(ivit_handle h, const int8_t *x, const int8_t *w, cons
     REQUIRE(h, bits == 8 || bits == 16, "bits must be 8 or 16");
     GemmArgs a = linear_args(x, w, bias, M, N, K);
     a.out = out; a.dy_ch = dy_ch;
+    if (use_gemm2(a)) return bits == 8 ? launch_gemm2<EPI_RQ8_CH>(h, a) : launch_gemm2<EPI_RQ16_CH>(h, a);
     return bits == 8 ? launch_gemm<false, EPI_RQ8_CH>(h, a, 1) : launch_gemm<false, EPI_RQ16_CH>(h, a, 1);
 }
 
@@ -137,6 +154,7 @@ int ivit_linear_i8_requant_residual(ivit_handle h, const int8_t *x, const int8_t
     REQUIRE(h, (K % 16) == 0, "K must be a multiple of 16");
     GemmArgs a = linear_args(x, w, bias, M, N, K);
     a.out = out; a.dy_ch = dy_ch; a.dy_main = dy_main; a.dy_res = dy_res; a.residual = residual;
+    if (use_gemm2(a)) return launch_gemm2<EPI_RQ16_CH_RES>(h, a);
     return launch_gemm<false, EPI_RQ16_CH_RES>(h, a, 1);
 }
 
@@ -151,6 +169,7 @@ int ivit_linear_i8_qkv(ivit_handle h, const int8_t *x, const int8_t *w, const in
     GemmArgs a = linear_args(x, w, bias, B * T, 3 * D, D);
     a.dy_ch = dy_ch; a.q = q; a.k = k; a.vt = vt;
     a.T = T; a.H = H; a.dh = dh; a.ldv = ldv; a.D = D;
+    if (use_gemm2(a)) return launch_gemm2<EPI_QKV>(h, a);
     return launch_gemm<false, EPI_QKV>(h, a, 1);
 }
 

@@ -153,6 +153,43 @@ def test_linear_i8_vs_numpy(H, M, N, K):
     assert np.array_equal(acc.cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (788, 384, 384), (300, 1152, 192), (197, 1000, 384),
+                                   (50, 10, 64), (513, 136, 1536), (394, 384, 48)])
+def test_linear_requant_epilogues_vs_oracle(H, M, N, K):
+    """a1+a3 fused epilogues (8-bit, 16-bit, 16-bit + residual) == oracle linear + requant.
+    K % 64 == 0 shapes take the global_load_lds kernel, the last one the generic kernel."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(M + N + K)
+    x = rng.integers(-128, 128, (M, K), dtype=np.int8)
+    w = rng.integers(-128, 128, (N, K), dtype=np.int8)
+    b = rng.integers(-2 ** 16, 2 ** 16, N).astype(np.int32)
+    acc = orc.linear_i8(x, w, b)
+    amax = float(np.abs(acc).max())
+    s_pre = (10 ** rng.uniform(-6, -4, N)).astype(np.float32)
+    s_pre[::5] *= 0.5
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    for bits in (8, 16):
+        s_out = np.float32(amax * float(s_pre.mean()) / 2 ** (bits - 1) * 2.0)
+        d = iv.freeze.dyadic(s_pre, s_out)
+        out = torch.empty(M, N, dtype={8: torch.int8, 16: torch.int16}[bits], device="cuda")
+        H.call("ivit_linear_i8_requant", P(xd), P(wd), P(bd), P(dev(d)), bits, P(out), M, N, K)
+        ref = orc.requant(acc, orc.dyadic(s_pre, s_out), bits)
+        assert np.array_equal(out.cpu().numpy().astype(np.int32), ref), (bits, M, N, K)
+    # residual form; exact-tie multipliers (ratio 0.5 / 1.5) exercise the fp64 fallback
+    res = rng.integers(-32768, 32768, (M, N)).astype(np.int16)
+    for s_mid, s_res, s_fin in [(3.1e-5, 7.7e-5, 9.1e-5), (1e-4, 3e-4, 2e-4)]:
+        d_ch = iv.freeze.dyadic(s_pre, np.float32(amax * float(s_pre.mean()) / 32768 * 2.0))
+        d_main = iv.freeze.dyadic(np.float32(s_mid), np.float32(s_fin))
+        d_res = iv.freeze.dyadic(np.float32(s_res), np.float32(s_fin))
+        out = torch.empty(M, N, dtype=torch.int16, device="cuda")
+        H.call("ivit_linear_i8_requant_residual", P(xd), P(wd), P(bd), P(dev(d_ch)), dyv(d_main), dyv(d_res),
+               P(dev(res)), P(out), M, N, K)
+        t = orc.requant(acc, orc.dyadic(s_pre, np.float32(amax * float(s_pre.mean()) / 32768 * 2.0)), 16)
+        ref = orc.requant(t, orc.dyadic(np.float32(s_mid), np.float32(s_fin)), 16, res.astype(np.int32),
+                          orc.dyadic(np.float32(s_res), np.float32(s_fin)))
+        assert np.array_equal(out.cpu().numpy().astype(np.int32), ref), (M, N, K, s_mid)
+
+
 def test_mfma_operand_order_asymmetric(H):
     """A = I (padded) against an asymmetric B catches a transposed C write."""
     K = 64
