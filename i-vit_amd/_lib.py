@@ -66,6 +66,7 @@ SIGNATURES = {
     "ivit_shiftgelu_requant_lut": [_P, _P, _L, _I, _P, _P],
     "ivit_layernorm": [_P, _P, _L, _I, _F, _P, _P, _P],
     "ivit_layernorm_requant": [_P, _P, _L, _I, _L, _F, _P, _P, _P, _P],
+    "ivit_debug_div": [_P, _P, _P, _P, _P, _L],
     "ivit_im2col_patch": [_P, _P, _I, _I, _I, _I, _I, _P],
     "ivit_embed_finish": [_P, _P, _P, _P, Dyadic, Dyadic, _P, _I, _I, _I],
 }

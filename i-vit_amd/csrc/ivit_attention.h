@@ -102,6 +102,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void attn_fused_kernel(AttnArgs p) 
     const float s = p.s_softmax;
     const float x0 = floorf(-1.0f / s);
     const float nx0 = 15.0f * x0;
+    const RcpC sr = rcp_prepare(s), x0r = rcp_prepare(x0);
     const int ntile = (T + 15) >> 4;       // live 16-key tiles
     const int nqt = (T + 15) >> 4;         // query tiles
     const int nvec = T >> 3, size = nvec >> 2;
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void attn_fused_kernel(AttnArgs p) 
         }
         qmax = max(qmax, __shfl_xor(qmax, 16));
         qmax = max(qmax, __shfl_xor(qmax, 32));
-        const float mx = requotient((float)qmax, s);
+        const float mx = requotient_c((float)qmax, sr);
 
         // ---- shift-exp; keys >= T contribute exactly 0
 #pragma unroll
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void attn_fused_kernel(AttnArgs p) 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     int t = j * 16 + g * 4 + r;
-                    float e = shift_exp(requotient(f[j][r], s) - mx, x0, nx0, 15);
+                    float e = shift_exp_c(requotient_c(f[j][r], sr) - mx, x0r, nx0, 15);
                     f[j][r] = t < T ? e : 0.f;
                 }
             }

@@ -38,6 +38,44 @@ __device__ __forceinline__ int clamp_b(double v) {
     return (int)v;
 }
 
+// ---- correctly-rounded fp32 division by a loop-invariant divisor --------------
+// Measured on MI355X (tools/ubench/valu_rates.hip): `a / b` (v_div_scale, v_rcp, 5 fma,
+// v_div_fmas, v_div_fixup) costs ~16x a v_mul_f32.  Every divisor on this path is a
+// per-layer or per-channel constant, so the reciprocal refinement is hoisted and the
+// quotient is produced by the same FMA tail as the compiler's IEEE expansion
+// (q1 = fma(fma(-d,q0,n), y, q0); q = fma(fma(-d,q1,n), y, q1)) — correctly rounded for
+// normal-range operands (no div_scale/div_fixup cases occur here: |n|,|d| in ~[1e-12,1e12]).
+// Pinned bit-for-bit against `/` on the GPU in tests/test_gpu_parity.py::test_lean_division.
+struct RcpC { float d, y; };
+__device__ __forceinline__ RcpC rcp_prepare(float d) {
+    float r = __builtin_amdgcn_rcpf(d);
+    float e = __builtin_fmaf(-d, r, 1.0f);
+    RcpC c;
+    c.d = d;
+    c.y = __builtin_fmaf(e, r, r);
+    return c;
+}
+__device__ __forceinline__ float lean_div(float n, RcpC c) {
+    float q0 = n * c.y;
+    float r0 = __builtin_fmaf(-c.d, q0, n);
+    float q1 = __builtin_fmaf(r0, c.y, q0);
+    float r1 = __builtin_fmaf(-c.d, q1, n);
+    return __builtin_fmaf(r1, c.y, q1);
+}
+// fl(fl(Q*s)/s) with the hoisted reciprocal
+__device__ __forceinline__ float requotient_c(float q, RcpC s) { return lean_div(q * s.d, s); }
+// shift_exp with hoisted reciprocal of x0
+__device__ __forceinline__ float shift_exp_c(float x, RcpC x0, float nx0, int n) {
+    float t = x + floorf(x * 0.5f);
+    t = t - floorf(x * 0.0625f);
+    t = fmaxf(t, nx0);
+    float q = floorf(lean_div(t, x0));
+    float r = t - x0.d * q;
+    float e = r * 0.5f - x0.d;
+    e = floorf(ldexpf(e, n - (int)q));
+    return fmaxf(e, 0.0f);
+}
+
 // ---- fp32-faithful pieces ---------------------------------------------------
 // value a consumer of (Q, s) sees: fl(fl(Q*s)/s)   (quant_modules.py:204-206 then
 // :94/:359/:426/:484).  Not always equal to Q.

@@ -77,6 +77,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const int16_t *__restric
     if (row >= rows) return;                        // whole 32-lane group exits together
     const int16_t *xp = x + row * row_stride;
     const float Cf = (float)C;
+    const RcpC sr = rcp_prepare(s);
 
     // pass 0: coalesced 16-byte loads -> fl(fl(Q*s)/s) -> LDS
     const int nch8 = C >> 3;
@@ -85,13 +86,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const int16_t *__restric
         v4f lo, hi;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            lo[e] = requotient((float)q[e], s);
-            hi[e] = requotient((float)q[4 + e], s);
+            lo[e] = requotient_c((float)q[e], sr);
+            hi[e] = requotient_c((float)q[4 + e], sr);
         }
         *reinterpret_cast<v4f *>(xr + c * 8) = lo;
         *reinterpret_cast<v4f *>(xr + c * 8 + 4) = hi;
     }
-    for (int k = nch8 * 8 + sub; k < C; k += 32) xr[k] = requotient((float)xp[k], s);
+    for (int k = nch8 * 8 + sub; k < C; k += 32) xr[k] = requotient_c((float)xp[k], sr);
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const int16_t *__restric
             float yi = floorf((y * F) * 0.5f);
             float o = yi + bi;
             float Xo = o * scv;
-            zz[e] = rintf(Xo / scv);
+            zz[e] = rintf(lean_div(Xo, rcp_prepare(scv)));
         }
         if (OUT8) {
             unsigned pk[2] = {0, 0};
@@ -173,12 +174,14 @@ __global__ __launch_bounds__(256) void shiftmax_kernel(const int8_t *__restrict_
     for (int j = lane; j < n; j += 64) qmax = max(qmax, (int)xp[j]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) qmax = max(qmax, __shfl_xor(qmax, o));
-    const float mx = requotient((float)qmax, s);
+    const RcpC sr = rcp_prepare(s);
+    const float mx = requotient_c((float)qmax, sr);
     const float x0 = floorf(-1.0f / s);
+    const RcpC x0r = rcp_prepare(x0);
     const float nx0 = 15.0f * x0;
     for (int j = lane; j < n; j += 64) {
-        float xt = requotient((float)xp[j], s);
-        er[j] = shift_exp(xt - mx, x0, nx0, 15);
+        float xt = requotient_c((float)xp[j], sr);
+        er[j] = shift_exp_c(xt - mx, x0r, nx0, 15);
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -362,5 +365,16 @@ __global__ __launch_bounds__(256) void shiftgelu_lut_kernel(const int8_t *__rest
             o[d] = (int)r;
         }
         *reinterpret_cast<v4i *>(out + row * C + c * 16) = o;
+    }
+}
+
+// diagnostics: lean_div vs the compiler's IEEE division, element-wise
+__global__ __launch_bounds__(256) void debug_div_kernel(const float *__restrict__ n, const float *__restrict__ d,
+                                                        float *__restrict__ q_ieee, float *__restrict__ q_lean,
+                                                        long long count) {
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < count) {
+        q_ieee[i] = n[i] / d[i];
+        q_lean[i] = lean_div(n[i], rcp_prepare(d[i]));
     }
 }

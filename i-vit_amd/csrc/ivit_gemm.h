@@ -41,6 +41,7 @@ struct GemmArgs {
     int8_t *q, *k, *vt;
     int T, H, dh, ldv, D;
     int tiles_n;
+    int dbg;   // debug/ablation switch (env IVIT_GEMM_DBG), 0 in production
 };
 
 #define GEMM_BM 128

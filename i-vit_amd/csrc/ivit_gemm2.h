@@ -10,10 +10,14 @@
 // so every MFMA-fragment ds_read_b128 is bank-conflict-free.  Tiles that share an A panel
 // are placed on the same XCD (private L2) by a bijective block-id remap.
 //
-// Requant: the reference arithmetic is rne((double(z)*m)*2^-e) (quant_utils.py:229-230).
-// The epilogue evaluates it through an fp32 path with a proven error bound and falls back
-// to the fp64 sequence whenever the bound cannot decide the rounding (near-ties, |z| >=
-// 2^24) — the result is always identical to the fp64 sequence.
+// Epilogue: the MFMA operand roles are swapped (weights = "A", activations = "B"), so a
+// lane holds ONE token and 4 CONSECUTIVE channels per register quad: four requantised
+// values pack into a dword for free.  Requant is the reference arithmetic
+// rne((double(z)*m)*2^-e) (quant_utils.py:229-230) evaluated as rne(double(z)*c) with
+// c = m*2^-e, which is exact in fp64 (m integer < 2^32, power-of-two scaling) — one
+// v_mul_f64, bit-identical.  (Measured on MI355X, tools/ubench/valu_rates.hip: v_mul_f64,
+// v_rndne_f64, v_cvt_* all cost ~1.7x a v_mul_f32, so an fp32 "fast path" buys nothing.)
+// Packed dwords are staged in LDS and leave as whole 128/256-byte rows (16 B per lane).
 #pragma once
 #include "ivit_gemm.h"
 
@@ -21,64 +25,15 @@
 #define G2_BN 128
 #define G2_BK 64
 #define G2_STAGE 24576          // 256*64 (A) + 128*64 (B)
-#define G2_SMEM (3 * G2_STAGE)  // 73728 >= 256*272 (int16 staging)
+#define G2_SMEM (3 * G2_STAGE)  // 73728 >= 256*264 (int16 staging)
+#define G2_LD8 136              // staged int8 row stride (bytes): 2-way-free ds_write_b32
+#define G2_LD16 264             // staged int16 row stride (bytes): conflict-free ds_write_b64
 
-// ---- exact requant with fp32 fast paths -------------------------------------
-struct RqF { float chi, clo; };
-
-__device__ __forceinline__ RqF rqf_make(double m, double r) {
-    double c = m * r;
-    RqF f;
-    f.chi = (float)c;
-    f.clo = (float)(c - (double)f.chi);
-    return f;
+__device__ __forceinline__ int rq_lean(int z, double c, int lo, int hi) {
+    int v = (int)__builtin_rint((double)z * c);   // cvt_i32_f64 saturates
+    return min(max(v, lo), hi);
 }
-
-// 8-bit: p = fl(z*chi) carries < |y|*1.2e-7 error; for |p| <= 200 that is < 2.4e-5, so
-// rint(p) == rne(y) whenever p is farther than 1e-4 from a tie; |p| > 200 clamps anyway.
-__device__ __forceinline__ int rq8_exact(int z, RqF f, double m, double r) {
-    float zf = (float)z;
-    float p = zf * f.chi;
-    float rp = rintf(p);
-    float d = fabsf(p - rp);
-    bool ok = ((d < 0.4999f) || (fabsf(p) > 200.0f)) && ((unsigned)(z + (1 << 24)) < (1u << 25));
-    int v = (int)fminf(fmaxf(rp, -128.0f), 127.0f);
-    if (!ok) v = clamp_b<8>(rq_f64((double)z, m, r));
-    return v;
-}
-
-// 16-bit: two-term product, y = p + e2 with |error| < |y|*2^-44; decide the rounding from
-// t = (p - rint(p)) + e2 unless t is within 1e-6 of +-0.5 (then the fp64 sequence decides).
-__device__ __forceinline__ int rq16_exact(int z, RqF f, double m, double r) {
-    float zf = (float)z;
-    float p = zf * f.chi;
-    float e1 = __builtin_fmaf(zf, f.chi, -p);
-    float e2 = __builtin_fmaf(zf, f.clo, e1);
-    float rp = rintf(p);
-    float t = (p - rp) + e2;
-    float at = fabsf(t);
-    bool ok = ((fabsf(at - 0.5f) > 1e-6f) || (fabsf(p) > 40000.0f)) && ((unsigned)(z + (1 << 24)) < (1u << 25));
-    float adj = at > 0.5f ? (t > 0.f ? 1.0f : -1.0f) : 0.0f;
-    int v = (int)fminf(fmaxf(rp + adj, -32768.0f), 32767.0f);
-    if (!ok) v = clamp_b<16>(rq_f64((double)z, m, r));
-    return v;
-}
-
-// unclamped variant for the two terms of the residual add (|result| < 2^22)
-__device__ __forceinline__ int rq16_wide(int z, RqF f, double m, double r) {
-    float zf = (float)z;
-    float p = zf * f.chi;
-    float e1 = __builtin_fmaf(zf, f.chi, -p);
-    float e2 = __builtin_fmaf(zf, f.clo, e1);
-    float rp = rintf(p);
-    float t = (p - rp) + e2;
-    float at = fabsf(t);
-    bool ok = (fabsf(at - 0.5f) > 1e-6f) && (fabsf(p) < 4194304.0f) && ((unsigned)(z + (1 << 24)) < (1u << 25));
-    float adj = at > 0.5f ? (t > 0.f ? 1.0f : -1.0f) : 0.0f;
-    int v = (int)(rp + adj);
-    if (!ok) v = clamp_b<32>(rq_f64((double)z, m, r));
-    return v;
-}
+__device__ __forceinline__ int rq_lean_wide(int z, double c) { return (int)__builtin_rint((double)z * c); }
 
 __device__ __forceinline__ void g2_issue(const int8_t *A, const int8_t *B, int lda, int ldb, int M, int N,
                                          int row0, int col0, int k0, char *stage, int tid) {
@@ -105,10 +60,10 @@ __device__ __forceinline__ void g2_issue(const int8_t *A, const int8_t *B, int l
 }
 
 template <int EPI>
-__global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs p) {
-    __shared__ __attribute__((aligned(16))) char smem[G2_SMEM];
+__global__ __launch_bounds__(512, 4) void gemm_glds_kernel(GemmArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[G2_SMEM + 1536];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5;
 
     // XCD-aware, bijective block -> tile map: each XCD owns a contiguous run of tiles,
     // n-fastest, so the blocks that share an A panel share one L2.
@@ -121,6 +76,23 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs p) {
     const int8_t *A = reinterpret_cast<const int8_t *>(p.A);
     const int8_t *B = p.B;
 
+    const int nk = p.K / G2_BK;
+    g2_issue(A, B, p.lda, p.ldb, p.M, p.N, row0, col0, 0, smem, tid);
+    if (nk > 1) g2_issue(A, B, p.lda, p.ldb, p.M, p.N, row0, col0, G2_BK, smem + G2_STAGE, tid);
+
+    // per-channel constants of this column block -> LDS (read back in the epilogue; the
+    // K-loop barriers order the write): c[n] = m*2^-e (exact in fp64), bias[n]
+    double *sC = reinterpret_cast<double *>(smem + G2_SMEM);
+    int *sBias = reinterpret_cast<int *>(smem + G2_SMEM + 1024);
+    if (tid < G2_BN) {
+        const int ch = col0 + tid;
+        const bool in = ch < p.N;
+        sC[tid] = in ? p.dy_ch[ch].m * p.dy_ch[ch].r : 0.0;
+        sBias[tid] = (in && p.bias) ? p.bias[ch] : 0;
+    }
+
+    // acc[i][j]: C^T sub-tiles — lane holds token (lane&31) of m-tile i and, per register
+    // quad g, the 4 consecutive channels 32j + 8g + 4*half + (0..3)
     v16i acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -128,10 +100,6 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs p) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
-
-    const int nk = p.K / G2_BK;
-    g2_issue(A, B, p.lda, p.ldb, p.M, p.N, row0, col0, 0, smem, tid);
-    if (nk > 1) g2_issue(A, B, p.lda, p.ldb, p.M, p.N, row0, col0, G2_BK, smem + G2_STAGE, tid);
 
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
@@ -145,7 +113,7 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs p) {
         const char *sB = sA + 16384;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            const int chunk = kk * 2 + (lane >> 5);
+            const int chunk = kk * 2 + half;
             v4i a[2], b[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -156,44 +124,55 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs p) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b[j], a[i], acc[i][j], 0, 0, 0);
         }
     }
     asm volatile("" ::: "memory");
+    if (p.dbg == 1) {   // ablation: main loop only
+        int sacc = 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc ^= acc[i][j][r];
+        if (sacc == 0x12345678) reinterpret_cast<int *>(p.out)[tid] = sacc;
+        return;
+    }
     __syncthreads();   // every wave done with the ring before it is reused as the staging tile
 
-    // ---- phase 1: per-lane requant of the accumulator fragments -> staged tile
-    double dm[2] = {0, 0}, dr[2] = {0, 0};
-    RqF fq[2];
-    int bias[2] = {0, 0};
+    constexpr bool OUT8 = (EPI == EPI_RQ8_CH || EPI == EPI_QKV);
+    // ---- phase 1: requant + pack 4 channels per lane -> staged tile [token][channel]
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        int col = min(col0 + wn * 64 + j * 32 + (lane & 31), p.N - 1);
-        if (p.bias) bias[j] = p.bias[col];
-        dm[j] = p.dy_ch[col].m;
-        dr[j] = p.dy_ch[col].r;
-        fq[j] = rqf_make(dm[j], dr[j]);
-    }
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int g = 0; g < 4; ++g) {
+            const int nl = wn * 64 + j * 32 + g * 8 + half * 4;
+            double c[4]; int bs[4];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int e = 0; e < 4; ++e) { c[e] = sC[nl + e]; bs[e] = sBias[nl + e]; }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int rl = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                int cl = wn * 64 + j * 32 + (lane & 31);
-                int v = acc[i][j][r] + bias[j];
-                if (EPI == EPI_RQ16_CH || EPI == EPI_RQ16_CH_RES) {
-                    int o = rq16_exact(v, fq[j], dm[j], dr[j]);
-                    *reinterpret_cast<int16_t *>(smem + rl * GEMM_SC16_LD + cl * 2) = (int16_t)o;
+            for (int i = 0; i < 2; ++i) {
+                const int ml = wm * 64 + i * 32 + (lane & 31);
+                if (OUT8) {
+                    unsigned w = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        w |= ((unsigned)rq_lean(acc[i][j][g * 4 + e] + bs[e], c[e], -128, 127) & 0xffu) << (8 * e);
+                    *reinterpret_cast<unsigned *>(smem + ml * G2_LD8 + nl) = w;
                 } else {
-                    int o = rq8_exact(v, fq[j], dm[j], dr[j]);
-                    *reinterpret_cast<int8_t *>(smem + rl * GEMM_SC8_LD + cl) = (int8_t)o;
+                    int o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = rq_lean(acc[i][j][g * 4 + e] + bs[e], c[e], -32768, 32767);
+                    v2i w = {(int)(((unsigned)o[0] & 0xffffu) | ((unsigned)o[1] << 16)),
+                             (int)(((unsigned)o[2] & 0xffffu) | ((unsigned)o[3] << 16))};
+                    *reinterpret_cast<v2i *>(smem + ml * G2_LD16 + nl * 2) = w;
                 }
             }
+        }
     __syncthreads();
 
-    // ---- phase 2: coalesced write-out
+    // ---- phase 2: whole rows out, 16 bytes per lane
     if (EPI == EPI_RQ8_CH) {
         int8_t *out = reinterpret_cast<int8_t *>(p.out);
 #pragma unroll
@@ -201,7 +180,9 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs p) {
             int id = tid + i * 512, row = id >> 3, c = id & 7;
             int grow = row0 + row, gcol = col0 + c * 16;
             if (grow < p.M && gcol < p.N) {
-                v4i v = *reinterpret_cast<const v4i *>(smem + row * GEMM_SC8_LD + c * 16);
+                const char *sp = smem + row * G2_LD8 + c * 16;
+                v2i lo = *reinterpret_cast<const v2i *>(sp), hi = *reinterpret_cast<const v2i *>(sp + 8);
+                v4i v = {lo[0], lo[1], hi[0], hi[1]};
                 int8_t *dst = out + (long long)grow * p.ldc + gcol;
                 if (gcol + 16 <= p.N && ((p.ldc & 15) == 0)) {
                     *reinterpret_cast<v4i *>(dst) = v;
@@ -212,13 +193,15 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs p) {
         }
     } else if (EPI == EPI_RQ16_CH || EPI == EPI_RQ16_CH_RES) {
         int16_t *out = reinterpret_cast<int16_t *>(p.out);
-        const RqF fm = rqf_make(p.dy_main.m, p.dy_main.r), fr = rqf_make(p.dy_res.m, p.dy_res.r);
+        const double cm = p.dy_main.m * p.dy_main.r, cr = p.dy_res.m * p.dy_res.r;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             int id = tid + i * 512, row = id >> 4, c = id & 15;
             int grow = row0 + row, gcol = col0 + c * 8;
             if (grow < p.M && gcol < p.N) {
-                v4i v = *reinterpret_cast<const v4i *>(smem + row * GEMM_SC16_LD + c * 16);
+                const char *sp = smem + row * G2_LD16 + c * 16;
+                v2i lo = *reinterpret_cast<const v2i *>(sp), hi = *reinterpret_cast<const v2i *>(sp + 8);
+                v4i v = {lo[0], lo[1], hi[0], hi[1]};
                 int16_t *dst = out + (long long)grow * p.ldc + gcol;
                 const bool vec = (gcol + 8 <= p.N) && ((p.ldc & 7) == 0);
                 if (EPI == EPI_RQ16_CH_RES) {
@@ -234,9 +217,9 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs p) {
                     for (int w = 0; w < 4; ++w) {
                         int t0 = (int)(short)(v[w] & 0xffff), t1 = v[w] >> 16;
                         int r0 = (int)(short)(rs[w] & 0xffff), r1 = rs[w] >> 16;
-                        // both terms are integers < 2^17: their sum is exact in int
-                        int o0 = rq16_wide(r0, fr, p.dy_res.m, p.dy_res.r) + rq16_wide(t0, fm, p.dy_main.m, p.dy_main.r);
-                        int o1 = rq16_wide(r1, fr, p.dy_res.m, p.dy_res.r) + rq16_wide(t1, fm, p.dy_main.m, p.dy_main.r);
+                        // both terms are integers < 2^31: the sum is the reference's fp64 sum
+                        int o0 = rq_lean_wide(r0, cr) + rq_lean_wide(t0, cm);
+                        int o1 = rq_lean_wide(r1, cr) + rq_lean_wide(t1, cm);
                         o0 = min(max(o0, -32768), 32767);
                         o1 = min(max(o1, -32768), 32767);
                         v[w] = (o0 & 0xffff) | (o1 << 16);
@@ -250,12 +233,15 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs p) {
             }
         }
     } else if (EPI == EPI_QKV) {
+        // rows-fastest mapping: a wave covers 64 consecutive tokens of one 16-channel chunk
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int id = tid + i * 512, row = id & 255, c = id >> 8;
             int grow = row0 + row, gcol = col0 + c * 16;
             if (grow < p.M && gcol < p.N) {
-                v4i v = *reinterpret_cast<const v4i *>(smem + row * GEMM_SC8_LD + c * 16);
+                const char *sp = smem + row * G2_LD8 + c * 16;
+                v2i lo = *reinterpret_cast<const v2i *>(sp), hi = *reinterpret_cast<const v2i *>(sp + 8);
+                v4i v = {lo[0], lo[1], hi[0], hi[1]};
                 int which = gcol / p.D, within = gcol - which * p.D;
                 int head = within / p.dh, d0 = within - head * p.dh;
                 int b = grow / p.T, t = grow - b * p.T;

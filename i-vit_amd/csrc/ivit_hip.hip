@@ -2,6 +2,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include "ivit_device.h"
 #include "ivit_elementwise.h"
@@ -103,6 +104,7 @@ template <int EPI>
 static int launch_gemm2(ivit_handle h, GemmArgs &a) {
     const int tm = (a.M + G2_BM - 1) / G2_BM;
     a.tiles_n = (a.N + G2_BN - 1) / G2_BN;
+    { static int dbg = -1; if (dbg < 0) { const char *e = getenv("IVIT_GEMM_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
     gemm_glds_kernel<EPI><<<dim3((unsigned)(tm * a.tiles_n)), 512, 0, h->stream>>>(a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -169,7 +171,8 @@ int ivit_linear_i8_qkv(ivit_handle h, const int8_t *x, const int8_t *w, const in
     GemmArgs a = linear_args(x, w, bias, B * T, 3 * D, D);
     a.dy_ch = dy_ch; a.q = q; a.k = k; a.vt = vt;
     a.T = T; a.H = H; a.dh = dh; a.ldv = ldv; a.D = D;
-    if (use_gemm2(a)) return launch_gemm2<EPI_QKV>(h, a);
+    if (use_gemm2(a) && (dh % 16) == 0)
+        return launch_gemm2<EPI_QKV>(h, a);
     return launch_gemm<false, EPI_QKV>(h, a, 1);
 }
 
@@ -382,6 +385,14 @@ int ivit_layernorm_requant(ivit_handle h, const int16_t *x, int64_t rows, int C,
     int st = set_dyn_lds(h, (const void *)layernorm_kernel<true>, lds);
     if (st) return st;
     layernorm_kernel<true><<<(unsigned)((rows + 7) / 8), 256, lds, h->stream>>>(x, rows, C, row_stride, scale, bias_int, sc, dy_ch, out8);
+    LAUNCH_CHECK(h);
+    return IVIT_OK;
+}
+
+int ivit_debug_div(ivit_handle h, const float *n, const float *d, float *q_ieee, float *q_lean, int64_t count) {
+    CHECK_H(h);
+    REQUIRE(h, n && d && q_ieee && q_lean && count > 0, "bad arguments");
+    debug_div_kernel<<<(unsigned)((count + 255) / 256), 256, 0, h->stream>>>(n, d, q_ieee, q_lean, count);
     LAUNCH_CHECK(h);
     return IVIT_OK;
 }

@@ -175,6 +175,12 @@ int ivit_embed_finish(ivit_handle h, const int16_t *patch16, const int32_t *z_cl
                       const int16_t *pos, ivit_dyadic dy_x, ivit_dyadic dy_pos, int16_t *x16,
                       int B, int T, int D);
 
+/* ---- diagnostics (used by the parity tests only) ------------------------------------
+ * q_ieee = n / d (compiler's correctly-rounded division) and q_lean = the hoisted-reciprocal
+ * FMA sequence the kernels use for constant divisors; must agree bit for bit.            */
+int ivit_debug_div(ivit_handle h, const float *n, const float *d, float *q_ieee, float *q_lean,
+                   int64_t count);
+
 #ifdef __cplusplus
 }
 #endif

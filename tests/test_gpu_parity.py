@@ -53,6 +53,32 @@ def test_library_loaded():
     assert lib.ivit_version() >= 100
 
 
+def test_lean_division(H):
+    """hoisted-reciprocal division == IEEE division, bit for bit, on the path's value ranges:
+    requotient (Q*s)/s, shift-exp t/x0, LayerNorm (o*sc)/sc."""
+    rng = np.random.default_rng(5)
+    cases = []
+    for s in (10 ** rng.uniform(-6, 0.5, 400)).astype(np.float32):      # (Q*s)/s, all int16 Q
+        q = np.arange(-32768, 32768, 1, dtype=np.float32)[rng.integers(0, 65536, 4096)]
+        cases.append(((q * s).astype(np.float32), np.full(4096, s, np.float32)))
+    for x0 in -rng.integers(1, 4000, 300).astype(np.float32):             # t / x0
+        t = -(rng.uniform(0, 400, 4096)).astype(np.float32)
+        cases.append((t, np.full(4096, x0, np.float32)))
+    for _ in range(300):                                                   # (o*sc)/sc, o ~ 2^28
+        sc = np.float32(rng.uniform(-1, 1) * 3e-5)
+        o = np.rint(rng.standard_normal(4096) * 2 ** 28).astype(np.float32)
+        cases.append(((o * sc).astype(np.float32), np.full(4096, sc, np.float32)))
+    n = np.concatenate([c[0] for c in cases])
+    d = np.concatenate([c[1] for c in cases])
+    nd, dd = dev(n), dev(d)
+    a = torch.empty_like(nd)
+    b = torch.empty_like(nd)
+    H.call("ivit_debug_div", P(nd), P(dd), P(a), P(b), n.size)
+    a, b = a.cpu().numpy(), b.cpu().numpy()
+    assert np.array_equal(a, (n / d).astype(np.float32))     # GPU IEEE division == host IEEE
+    assert np.array_equal(a.view(np.int32), b.view(np.int32)), f"{(a != b).sum()} of {n.size} differ"
+
+
 def test_quantize_input(H, ops_golden):
     g = ops_golden
     x = dev(g["quant_in/x"])
