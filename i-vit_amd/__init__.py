@@ -6,8 +6,26 @@ from . import _lib  # noqa
 from ._lib import IvitError, build  # noqa
 
 
+_LAZY = {
+    "ViTEngine": ("engine", "ViTEngine"),
+    "QuantLinear": ("quant_modules", "QuantLinear"), "QuantAct": ("quant_modules", "QuantAct"),
+    "QuantMatMul": ("quant_modules", "QuantMatMul"), "QuantConv2d": ("quant_modules", "QuantConv2d"),
+    "IntLayerNorm": ("quant_modules", "IntLayerNorm"), "IntGELU": ("quant_modules", "IntGELU"),
+    "IntSoftmax": ("quant_modules", "IntSoftmax"), "to_int": ("quant_modules", "to_int"),
+    "Mlp": ("layers_quant", "Mlp"), "PatchEmbed": ("layers_quant", "PatchEmbed"),
+    "VisionTransformer": ("vit_quant", "VisionTransformer"),
+    "deit_tiny_patch16_224": ("vit_quant", "deit_tiny_patch16_224"),
+    "deit_small_patch16_224": ("vit_quant", "deit_small_patch16_224"),
+    "deit_base_patch16_224": ("vit_quant", "deit_base_patch16_224"),
+    "vit_base_patch16_224": ("vit_quant", "vit_base_patch16_224"),
+    "vit_large_patch16_224": ("vit_quant", "vit_large_patch16_224"),
+    "freeze_model": ("model_utils", "freeze_model"), "unfreeze_model": ("model_utils", "unfreeze_model"),
+}
+
+
 def __getattr__(name):
-    if name == "ViTEngine":
-        from .engine import ViTEngine
-        return ViTEngine
+    if name in _LAZY:
+        import importlib
+        mod, attr = _LAZY[name]
+        return getattr(importlib.import_module("." + mod, __name__), attr)
     raise AttributeError(name)

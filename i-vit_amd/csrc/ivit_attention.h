@@ -103,6 +103,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void attn_fused_kernel(AttnArgs p) 
     const float x0 = floorf(-1.0f / s);
     const float nx0 = 15.0f * x0;
     const RcpC sr = rcp_prepare(s), x0r = rcp_prepare(x0);
+    const double c_qk = p.dy_qk.m * p.dy_qk.r, c_pv = p.dy_pv.m * p.dy_pv.r;
     const int ntile = (T + 15) >> 4;       // live 16-key tiles
     const int nqt = (T + 15) >> 4;         // query tiles
     const int nvec = T >> 3, size = nvec >> 2;
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void attn_fused_kernel(AttnArgs p) 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     int t = j * 16 + g * 4 + r;
-                    int v = clamp_b<8>(rq_f64((double)acc[r], p.dy_qk.m, p.dy_qk.r));
+                    int v = rq_c((double)acc[r], c_qk, -128, 127);
                     f[j][r] = (float)v;
                     if (t < T) qmax = max(qmax, v);
                 }
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void attn_fused_kernel(AttnArgs p) 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 int v = (int)((unsigned)oL[dt][r] + ((unsigned)oH[dt][r] << 8) + ((unsigned)cs << 14));
-                int o = clamp_b<8>(rq_f64((double)v, p.dy_pv.m, p.dy_pv.r));
+                int o = rq_c((double)v, c_pv, -128, 127);
                 so[(g * 4 + r) * 64 + dt * 16 + qi] = (char)o;
             }
         }

@@ -38,6 +38,14 @@ __device__ __forceinline__ int clamp_b(double v) {
     return (int)v;
 }
 
+// lean form of the same requant: c = m*2^-e is exact in fp64 (m integer <= 2^31, power-of-two
+// scaling), so fl64(z*c) == fl64(z*m)*2^-e: one v_mul_f64; v_cvt_i32_f64 saturates and the
+// clamp is an integer med3.  Bit-identical to rq_f64 + clamp_b.
+__device__ __forceinline__ int rq_c(double z, double c, int lo, int hi) {
+    int v = (int)__builtin_rint(z * c);
+    return min(max(v, lo), hi);
+}
+
 // ---- correctly-rounded fp32 division by a loop-invariant divisor --------------
 // Measured on MI355X (tools/ubench/valu_rates.hip): `a / b` (v_div_scale, v_rcp, 5 fma,
 // v_div_fmas, v_div_fixup) costs ~16x a v_mul_f32.  Every divisor on this path is a

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const int16_t *__restric
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 ivit_dyadic d = dy[c * 8 + e];
-                int v = clamp_b<8>(rq_f64((double)zz[e], d.m, d.r));
+                int v = rq_c((double)zz[e], d.m * d.r, -128, 127);
                 pk[e >> 2] |= ((unsigned)v & 0xffu) << (8 * (e & 3));
             }
             *reinterpret_cast<v2i *>(reinterpret_cast<int8_t *>(out) + row * C + c * 8) = v2i{(int)pk[0], (int)pk[1]};

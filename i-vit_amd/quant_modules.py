@@ -1,0 +1,396 @@
+"""Drop-in operator surface: the seven classes of the reference
+`models/quantization_utils/quant_modules.py` (same names, constructor arguments, error
+behaviour and `forward(x, scale...) -> (y, scale)` shape), running on MI355X through the
+C-ABI of include/ivit.h.
+
+Difference from the reference, by design: activations travel as INTEGER device tensors plus
+an fp32 scale (host tensor), not as fp32 "integer*scale" tensors — the kernels re-derive
+fl(Q*s) where its rounding matters.  A fake-quant fp32 activation
+`X` with scale `s` from reference code converts with `to_int(X, s)`.
+
+Only the frozen ("fixed") inference path is implemented on the device (SURVEY.md §8 rows
+a1-a13); calibration (`running_stat=True` statistics) is the host-side next step (§8f N1):
+set `act_scaling_factor` from a calibrated reference checkpoint or `set_scale()`.
+There is no CPU fallback: without the HIP library / a GPU every forward raises.
+"""
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from . import freeze as fz
+
+_P = ctypes.c_void_p
+_handles = {}
+
+
+def handle(device):
+    """one ivit_handle per device, bound to torch's current stream at each call"""
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise _lib.IvitError("ivit_amd operators run on a HIP device only (no CPU fallback)")
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    h = _handles.get(idx)
+    if h is None:
+        h = _handles[idx] = _lib.Handle(idx, torch.cuda.current_stream(idx).cuda_stream)
+    h.set_stream(torch.cuda.current_stream(idx).cuda_stream)
+    return h
+
+
+def _ptr(t):
+    return _P(t.data_ptr())
+
+
+def _f32(s):
+    """scale -> numpy float32 array (host)"""
+    if isinstance(s, torch.Tensor):
+        s = s.detach().cpu().numpy()
+    return np.atleast_1d(np.asarray(s, np.float32)).reshape(-1)
+
+
+def _dyv(d):
+    return _lib.Dyadic(float(d[0, 0]), float(d[0, 1]))
+
+
+def to_int(x_fp32, scale, dtype=torch.int32):
+    """integer view of a reference-style fake-quant tensor: rne(x / s) (quant_utils.py:220)"""
+    s = torch.as_tensor(_f32(scale), device=x_fp32.device)
+    return torch.round(x_fp32 / s).to(dtype)
+
+
+class _DyCache:
+    """device dyadic tables keyed by the (pre-scale bytes, own scale) pair — the reference
+    recomputes them with a host Decimal loop on every call (quant_utils.py:150-175)."""
+
+    def __init__(self):
+        self.c = {}
+
+    def get(self, s_pre, s_out, device):
+        key = (s_pre.tobytes(), np.float32(s_out).tobytes(), str(device))
+        v = self.c.get(key)
+        if v is None:
+            d = fz.dyadic(s_pre, s_out)
+            v = self.c[key] = (d, torch.from_numpy(d).to(device))
+        return v
+
+
+class QuantLinear(nn.Linear):
+    """reference quant_modules.py:12-97"""
+
+    def __init__(self, in_features, out_features, bias=True, weight_bit=8, bias_bit=32, per_channel=True,
+                 quant_mode="symmetric"):
+        super().__init__(in_features, out_features, bias)
+        self.weight_bit, self.per_channel, self.bias_bit = weight_bit, per_channel, bias_bit
+        self.quantize_bias = bias_bit is not None
+        self.quant_mode = quant_mode
+        if quant_mode == "asymmetric":
+            raise NotImplementedError("unsupported quant mode: {}".format(quant_mode))
+        if quant_mode != "symmetric":
+            raise ValueError("unknown quant mode: {}".format(quant_mode))
+        if weight_bit != 8 or bias_bit != 32:
+            raise NotImplementedError("the MI355X path implements 8-bit weights / 32-bit bias")
+        self.register_buffer("fc_scaling_factor", torch.zeros(out_features))
+        self.register_buffer("weight_integer", torch.zeros_like(self.weight))
+        if self.bias is not None:
+            self.register_buffer("bias_integer", torch.zeros_like(self.bias))
+        self._frozen = None
+
+    def fix(self):
+        pass
+
+    def unfix(self):
+        pass
+
+    def _prepare(self, s_x, device):
+        key = (np.float32(s_x).tobytes(), str(device))
+        if self._frozen is not None and self._frozen[0] == key:
+            return self._frozen[1]
+        if not self.per_channel:
+            raise Exception("For weight, we only support per_channel quantization.")
+        w = self.weight.detach().cpu().numpy()
+        w_int, s_w = fz.quantize_weight(w)
+        if self.bias is not None:
+            b_int, s_b = fz.quantize_bias(self.bias.detach().cpu().numpy(), s_w, s_x)
+        else:
+            b_int, s_b = None, (s_w * np.float32(s_x)).astype(np.float32)
+        c = dict(w=torch.from_numpy(w_int).to(device),
+                 b=None if b_int is None else torch.from_numpy(b_int).to(device), s_b=s_b)
+        self.fc_scaling_factor = torch.from_numpy(s_w)
+        self.weight_integer = torch.from_numpy(w_int.astype(np.float32))
+        if b_int is not None:
+            self.bias_integer = torch.from_numpy(b_int.astype(np.float32))
+        self._frozen = (key, c)
+        return c
+
+    def forward(self, x, prev_act_scaling_factor=None):
+        """x: int8 device tensor [..., in]; returns (int32 accumulators [..., out], scale[out])"""
+        s_x = _f32(prev_act_scaling_factor)
+        if s_x.size != 1:
+            raise ValueError("QuantLinear expects a per-tensor input scale")
+        if x.dtype != torch.int8:
+            raise TypeError("QuantLinear input must be int8 (use QuantAct first)")
+        c = self._prepare(s_x[0], x.device)
+        x2 = x.reshape(-1, self.in_features).contiguous()
+        acc = torch.empty(x2.shape[0], self.out_features, dtype=torch.int32, device=x.device)
+        handle(x.device).call("ivit_linear_i8", _ptr(x2), _ptr(c["w"]), _ptr(c["b"]) if c["b"] is not None else None,
+                              _ptr(acc), x2.shape[0], self.out_features, self.in_features)
+        return acc.reshape(*x.shape[:-1], self.out_features), torch.from_numpy(c["s_b"])
+
+
+class QuantAct(nn.Module):
+    """reference quant_modules.py:100-206 (frozen path: fixedpoint_mul, quant_utils.py:192-253)"""
+
+    def __init__(self, activation_bit=8, act_range_momentum=0.95, running_stat=True, per_channel=False,
+                 quant_mode="symmetric"):
+        super().__init__()
+        self.activation_bit, self.act_range_momentum = activation_bit, act_range_momentum
+        self.running_stat, self.quant_mode, self.per_channel = running_stat, quant_mode, per_channel
+        self.min_val = torch.zeros(1)
+        self.max_val = torch.zeros(1)
+        self.register_buffer("act_scaling_factor", torch.zeros(1))
+        if quant_mode == "asymmetric":
+            raise NotImplementedError("unsupported quant mode: {}".format(quant_mode))
+        if quant_mode != "symmetric":
+            raise ValueError("unknown quant mode: {}".format(quant_mode))
+        self._dy = _DyCache()
+
+    def fix(self):
+        self.running_stat = False
+
+    def unfix(self):
+        self.running_stat = True
+
+    def set_scale(self, s):
+        self.act_scaling_factor = torch.tensor([float(np.float32(s))], dtype=torch.float32)
+
+    def set_range(self, min_val, max_val):
+        """scale from a calibrated range exactly like quant_utils.py:51-69"""
+        self.set_scale(fz.symmetric_scale(min_val, max_val, self.activation_bit))
+
+    def forward(self, x, pre_act_scaling_factor=None, identity=None, identity_scaling_factor=None):
+        if self.running_stat:
+            raise NotImplementedError("activation-range calibration (running_stat=True) is host-side future "
+                                      "work (SURVEY.md §8f N1): call fix()/freeze_model after setting scales")
+        s_out = np.float32(self.act_scaling_factor.reshape(-1)[0].item())
+        if not s_out > 0:
+            raise ValueError("QuantAct has no scale: load act_scaling_factor or call set_scale()")
+        bits = self.activation_bit
+        h = handle(x.device)
+        out_dt = {8: torch.int8, 16: torch.int16, 32: torch.int32}.get(bits)
+        if out_dt is None:
+            raise NotImplementedError("activation_bit must be 8, 16 or 32 on the MI355X path")
+        if pre_act_scaling_factor is None:
+            if bits != 8 or not x.is_floating_point():
+                raise NotImplementedError("input quantisation is implemented for fp32 -> 8 bit")
+            xc = x.contiguous().float()
+            q = torch.empty(xc.shape, dtype=torch.int8, device=x.device)
+            h.call("ivit_quantize_input_f32", _ptr(xc), float(s_out), _ptr(q), xc.numel())
+            return q, self.act_scaling_factor
+        s_pre = _f32(pre_act_scaling_factor)
+        C = x.shape[-1]
+        if s_pre.size not in (1, C):
+            raise NotImplementedError("scale must be per-tensor or per-channel on the last dim")
+        d, dd = self._dy.get(s_pre, s_out, x.device)
+        zi = di = None
+        if identity is not None:
+            s_id = _f32(identity_scaling_factor)
+            if s_id.size != 1:
+                raise NotImplementedError("identity scale must be per-tensor")
+            _, di = self._dy.get(s_id, s_out, x.device)
+            zi = identity.to(torch.int32).expand(x.shape).contiguous()
+        out = torch.empty(x.shape, dtype=out_dt, device=x.device)
+        rows = x.numel() // C
+        if x.dtype == torch.float32:
+            xc = x.contiguous()
+            h.call("ivit_requant_f32", _ptr(xc), _ptr(dd), d.shape[0], _ptr(zi) if zi is not None else None,
+                   _ptr(di) if di is not None else None, bits, _ptr(out), rows, C)
+        else:
+            xc = x.to(torch.int32).contiguous()
+            h.call("ivit_requant_i32", _ptr(xc), _ptr(dd), d.shape[0], _ptr(zi) if zi is not None else None,
+                   _ptr(di) if di is not None else None, bits, _ptr(out), rows, C)
+        return out, self.act_scaling_factor
+
+
+class QuantMatMul(nn.Module):
+    """reference quant_modules.py:209-228; A int8 (or 16-bit Shiftmax output), B int8"""
+
+    def __init__(self):
+        super().__init__()
+        self.register_buffer("act_scaling_factor", torch.zeros(1))
+
+    def fix(self):
+        pass
+
+    def unfix(self):
+        pass
+
+    def forward(self, A, pre_act_scaling_factor_A, B, pre_act_scaling_factor_B):
+        sA, sB = _f32(pre_act_scaling_factor_A), _f32(pre_act_scaling_factor_B)
+        s_out = (sA * sB).astype(np.float32)
+        self.act_scaling_factor = torch.from_numpy(s_out)
+        if B.dtype != torch.int8:
+            raise TypeError("QuantMatMul: B must be int8")
+        M, K = A.shape[-2], A.shape[-1]
+        N = B.shape[-1]
+        batch = A.shape[:-2]
+        nb = int(np.prod(batch)) if len(batch) else 1
+        Kp = (K + 15) // 16 * 16
+        # "NT" operand: B^T with K contiguous, row stride padded to 16 (layout plumbing)
+        Bt = torch.zeros(nb, N, Kp, dtype=torch.int8, device=A.device)
+        Bt[:, :, :K] = B.reshape(nb, K, N).transpose(1, 2)
+        C = torch.empty(nb, M, N, dtype=torch.int32, device=A.device)
+        h = handle(A.device)
+        if A.dtype == torch.int8:
+            Ap = torch.zeros(nb, M, Kp, dtype=torch.int8, device=A.device)
+            Ap[:, :, :K] = A.reshape(nb, M, K)
+            h.call("ivit_bmm_nt_i8", _ptr(Ap), _ptr(Bt), _ptr(C), nb, M, N, K, Kp, Kp, N, M * Kp, N * Kp, M * N)
+        else:
+            Ap = torch.zeros(nb, M, Kp, dtype=torch.int16, device=A.device)   # uint16 payload
+            Ap[:, :, :K] = A.reshape(nb, M, K).to(torch.int32).to(torch.int16)
+            h.call("ivit_bmm_nt_u16i8", _ptr(Ap), _ptr(Bt), _ptr(C), nb, M, N, K, Kp, Kp, N, M * Kp, N * Kp, M * N)
+        return C.reshape(*batch, M, N), self.act_scaling_factor
+
+
+class QuantConv2d(nn.Conv2d):
+    """reference quant_modules.py:231-330; the patch-embedding case kernel == stride, no padding"""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 bias=True, weight_bit=8, bias_bit=32, quant_mode="symmetric", per_channel=True,
+                 weight_percentile=0):
+        super().__init__(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias)
+        self.weight_bit, self.quant_mode, self.per_channel = weight_bit, quant_mode, per_channel
+        self.weight_percentile, self.bias_bit = weight_percentile, bias_bit
+        self.quantize_bias = bias_bit is not None
+        self.register_buffer("conv_scaling_factor", torch.zeros(out_channels))
+        self.register_buffer("weight_integer", torch.zeros_like(self.weight))
+        self.register_buffer("bias_integer", torch.zeros_like(self.bias))
+        self._frozen = None
+
+    def fix(self):
+        pass
+
+    def unfix(self):
+        pass
+
+    def forward(self, x, pre_act_scaling_factor=None):
+        if self.quant_mode == "asymmetric":
+            raise NotImplementedError("unsupported quant mode: {}".format(self.quant_mode))
+        if self.quant_mode != "symmetric":
+            raise ValueError("unknown quant mode: {}".format(self.quant_mode))
+        if not self.per_channel:
+            raise Exception("For weight, we only support per_channel quantization.")
+        P = self.kernel_size[0]
+        if (self.kernel_size != self.stride or self.kernel_size[0] != self.kernel_size[1] or
+                any(self.padding) or self.groups != 1 or any(d != 1 for d in self.dilation)):
+            raise NotImplementedError("QuantConv2d on MI355X: non-overlapping patch convolution only")
+        s_x = _f32(pre_act_scaling_factor)[0]
+        key = (np.float32(s_x).tobytes(), str(x.device))
+        if self._frozen is None or self._frozen[0] != key:
+            w_int, s_w = fz.quantize_weight(self.weight.detach().cpu().numpy())
+            b_int, s_b = fz.quantize_bias(self.bias.detach().cpu().numpy(), s_w, s_x)
+            self.conv_scaling_factor = torch.from_numpy(s_w)
+            self._frozen = (key, dict(w=torch.from_numpy(w_int.reshape(w_int.shape[0], -1)).to(x.device),
+                                      b=torch.from_numpy(b_int).to(x.device), s_b=s_b))
+        c = self._frozen[1]
+        B, Cin, Hh, Ww = x.shape
+        K = Cin * P * P
+        rows = torch.empty(B * (Hh // P) * (Ww // P), K, dtype=torch.int8, device=x.device)
+        h = handle(x.device)
+        xc = x.contiguous()
+        h.call("ivit_im2col_patch", _ptr(xc), B, Cin, Hh, Ww, P, _ptr(rows))
+        acc = torch.empty(rows.shape[0], self.out_channels, dtype=torch.int32, device=x.device)
+        h.call("ivit_linear_i8", _ptr(rows), _ptr(c["w"]), _ptr(c["b"]), _ptr(acc), rows.shape[0],
+               self.out_channels, K)
+        y = acc.reshape(B, Hh // P, Ww // P, self.out_channels).permute(0, 3, 1, 2)
+        return y, torch.from_numpy(c["s_b"]).view(1, -1, 1, 1)
+
+
+class IntLayerNorm(nn.LayerNorm):
+    """reference quant_modules.py:333-386 (I-LayerNorm)"""
+
+    def __init__(self, normalized_shape, eps=1e-5, elementwise_affine=True):
+        super().__init__(normalized_shape, eps, elementwise_affine)
+        self.dim_sqrt = None
+        self.register_buffer("norm_scaling_factor", torch.zeros(1))
+        self.register_buffer("bias_integer", torch.zeros_like(self.bias))
+        self._frozen = None
+
+    def fix(self):
+        pass
+
+    def unfix(self):
+        pass
+
+    def forward(self, x, scaling_factor=None):
+        """x int16 [B, N, C]; returns (z float32 integer-valued [B,N,C], scale[C]) — z is the
+        integer the following QuantAct derives (it can exceed int32)."""
+        s = _f32(scaling_factor)[0]
+        if self._frozen is None or self._frozen[0] != str(x.device):
+            bi, sc = fz.layernorm_constants(self.weight.detach().cpu().numpy(), self.bias.detach().cpu().numpy())
+            self._frozen = (str(x.device), torch.from_numpy(bi).to(x.device), torch.from_numpy(sc).to(x.device), sc)
+            self.bias_integer = torch.from_numpy(bi)
+            self.norm_scaling_factor = torch.from_numpy(sc)
+        _, bi_d, sc_d, sc = self._frozen
+        C = x.shape[-1]
+        xc = x.to(torch.int16).contiguous()
+        z = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        handle(x.device).call("ivit_layernorm", _ptr(xc), xc.numel() // C, C, float(s), _ptr(bi_d), _ptr(sc_d), _ptr(z))
+        return z, torch.from_numpy(sc)
+
+
+class IntGELU(nn.Module):
+    """reference quant_modules.py:389-445 (ShiftGELU)"""
+
+    def __init__(self, output_bit=8):
+        super().__init__()
+        self.output_bit = output_bit
+        self.n = 23
+        self.register_buffer("act_scaling_factor", torch.zeros(1))
+        if output_bit != 8:
+            raise NotImplementedError("ShiftGELU on MI355X: 8-bit sigmoid (the reference default)")
+
+    def fix(self):
+        pass
+
+    def unfix(self):
+        pass
+
+    def forward(self, x, scaling_factor=None):
+        s = np.float32(_f32(scaling_factor)[0])
+        C = x.shape[-1]
+        xc = x.contiguous()
+        out = torch.empty(x.shape, dtype=torch.int16, device=x.device)
+        handle(x.device).call("ivit_shiftgelu", _ptr(xc), xc.numel() // C, C, float(s), _ptr(out))
+        s_out = np.float32(s * np.float32(1.0 / 2 ** (self.output_bit - 1)))
+        self.act_scaling_factor = torch.tensor([float(s_out)])
+        return out, self.act_scaling_factor
+
+
+class IntSoftmax(nn.Module):
+    """reference quant_modules.py:448-497 (Shiftmax); output int32 tensor holding 0..2^(b-1)"""
+
+    def __init__(self, output_bit=8):
+        super().__init__()
+        self.output_bit = output_bit
+        self.n = 15
+        self.register_buffer("act_scaling_factor", torch.zeros(1))
+        if output_bit not in (8, 16):
+            raise NotImplementedError("Shiftmax on MI355X: 8- or 16-bit output")
+
+    def fix(self):
+        pass
+
+    def unfix(self):
+        pass
+
+    def forward(self, x, scaling_factor):
+        s = np.float32(_f32(scaling_factor)[0])
+        n = x.shape[-1]
+        xc = x.contiguous()
+        out = torch.empty(x.shape, dtype=torch.int16, device=x.device)    # uint16 payload
+        handle(x.device).call("ivit_shiftmax", _ptr(xc), xc.numel() // n, n, n, float(s), self.output_bit,
+                              _ptr(out), n)
+        self.act_scaling_factor = torch.tensor([1.0 / 2 ** (self.output_bit - 1)])
+        return out.to(torch.int32) & 0xFFFF, self.act_scaling_factor

@@ -325,3 +325,55 @@ def test_vit_forward_vs_oracle_residual_stream():
     x_last = eng.last_x.cpu().numpy().reshape(3, cfg.num_tokens, cfg.embed_dim)
     assert np.array_equal(x_last, cap[f"blocks.{cfg.depth - 1}.qact4"].astype(np.int16))
     assert np.array_equal(logits, ref_logits)
+
+
+@pytest.mark.parametrize("fname", ["micro_vit2h_b3.npz", "deit_tiny_b1.npz"])
+def test_operator_surface_model_golden(fname):
+    """the reference-shaped module chain (one C-ABI call per operator) reproduces the
+    reference's integers: every captured site (micro) / final logits (DeiT-T)."""
+    g = load_golden(fname)
+    cfg = iv.CONFIGS[str(g["cfg_name"])]
+    m = iv.VisionTransformer(img_size=cfg.img_size, patch_size=cfg.patch_size, num_classes=cfg.num_classes,
+                             embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads, mlp_ratio=4)
+    m.load_float_weights(iv.make_vit_weights(cfg, int(g["seed"]))).load_act_scales(golden_scales(g))
+    iv.freeze_model(m)
+    imgs = iv.make_images_int8(cfg, int(g["batch"]), int(g["images_seed"]))
+    cap = {}
+    hooks = []
+    if fname.startswith("micro"):
+        for name, mod in m.named_modules():
+            if f"site/{name}" in g.files:
+                hooks.append(mod.register_forward_hook(lambda mod, i, o, name=name: cap.__setitem__(name, o[0])))
+    with torch.no_grad():
+        acc, scale = m(dev(imgs))
+    assert np.array_equal(acc.cpu().numpy(), g["logits_int"])
+    assert np.array_equal(scale.numpy(), g["logits_scale"])
+    for name, t in cap.items():
+        ref = g["site/" + name]
+        got = t.cpu().numpy()
+        if name == "patch_embed.proj":
+            got = got.reshape(got.shape[0], got.shape[1], -1).transpose(0, 2, 1)
+        if name == "norm":
+            got = got[:, 0]
+        assert np.array_equal(got.reshape(ref.shape).astype(np.float64), ref.astype(np.float64)), name
+    # the fused engine compiled from the same module agrees too
+    eng = m.compile()
+    assert np.array_equal(eng.forward(dev(imgs)).cpu().numpy(), g["logits_int"])
+
+
+def test_operator_error_behaviour():
+    """same exceptions as the reference constructors (quant_modules.py:46-48,143-145,77)"""
+    with pytest.raises(NotImplementedError):
+        iv.QuantLinear(8, 8, quant_mode="asymmetric")
+    with pytest.raises(ValueError):
+        iv.QuantLinear(8, 8, quant_mode="none")
+    with pytest.raises(NotImplementedError):
+        iv.QuantAct(quant_mode="asymmetric")
+    with pytest.raises(ValueError):
+        iv.QuantAct(quant_mode="bogus")
+    lin = iv.QuantLinear(64, 16, per_channel=False)
+    with pytest.raises(Exception):
+        lin(torch.zeros(4, 64, dtype=torch.int8, device="cuda"), torch.tensor(0.1))
+    act = iv.QuantAct()   # running_stat=True: calibration is not on the device path
+    with pytest.raises(NotImplementedError):
+        act(torch.zeros(4, 8, dtype=torch.int32, device="cuda"), torch.tensor(0.1))
