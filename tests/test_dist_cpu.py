@@ -1,0 +1,73 @@
+"""world_size-2 gloo test of the multi-GPU plumbing (runs on CPU): rank 0 freezes and packs
+the integer constants, every rank receives identical bytes; image shards are disjoint,
+contiguous and cover the batch."""
+import hashlib
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import load_golden, golden_scales
+import ivit_amd as iv
+from ivit_amd import dist as ivdist
+from ivit_amd.engine import pack_constants
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = load_golden("micro_vit_b2.npz")
+    cfg = iv.CONFIGS[str(g["cfg_name"])]
+    consts = f32 = None
+    if rank == 0:
+        consts, f32 = iv.freeze.freeze_vit(cfg, iv.make_vit_weights(cfg, int(g["seed"])), golden_scales(g))
+    blob, table, f32r = ivdist.broadcast_constants(consts, f32, rank, world, "cpu")
+    digest = hashlib.sha256(blob.numpy().tobytes()).hexdigest()
+    lo, hi = ivdist.shard_range(37, rank, world)
+    q.put((rank, digest, sorted(table)[:3], len(table), f32r["ln.s"], lo, hi))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_broadcast_and_sharding_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, d0, k0, n0, s0, lo0, hi0), (r1, d1, k1, n1, s1, lo1, hi1) = res
+    assert d0 == d1 and k0 == k1 and n0 == n1 and s0 == s1
+    assert (lo0, hi0, lo1, hi1) == (0, 19, 19, 37)
+    # the broadcast bytes are exactly rank 0's packed constants
+    g = load_golden("micro_vit_b2.npz")
+    cfg = iv.CONFIGS[str(g["cfg_name"])]
+    consts, _ = iv.freeze.freeze_vit(cfg, iv.make_vit_weights(cfg, int(g["seed"])), golden_scales(g))
+    blob, _ = pack_constants(consts)
+    assert hashlib.sha256(blob.tobytes()).hexdigest() == d0
+
+
+def test_shard_range_covers_batch():
+    for total in (1, 7, 256, 513):
+        for world in (1, 2, 3, 8):
+            parts = [ivdist.shard_range(total, r, world) for r in range(world)]
+            assert parts[0][0] == 0 and parts[-1][1] == total
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in parts]
+            assert max(sizes) - min(sizes) <= 1
