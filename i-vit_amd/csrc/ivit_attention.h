@@ -42,7 +42,7 @@ struct AttCfg {
     static constexpr int SK_BYTES = TK * 64;
     static constexpr int SV_BYTES = 64 * VS;
     static constexpr int SO_BYTES = ATT_WAVES * 1024;
-    static constexpr int SMEM = SK_BYTES + SV_BYTES + SO_BYTES + 256;
+    static constexpr int SMEM = SK_BYTES + SV_BYTES + SO_BYTES + 256 + 1024;
 };
 
 template <int NB>
@@ -53,6 +53,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void attn_fused_kernel(AttnArgs p) 
     char *sV = dsmem + C::SK_BYTES;
     char *sO = sV + C::SV_BYTES;
     int *sCol = reinterpret_cast<int *>(sO + C::SO_BYTES);
+    float *sXq = reinterpret_cast<float *>(sO + C::SO_BYTES + 256);   // fl(fl(Q*s)/s) for Q = -128..127
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
@@ -89,6 +90,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void attn_fused_kernel(AttnArgs p) 
 #pragma unroll
         for (int g = 0; g < 4; ++g) *reinterpret_cast<int *>(dst + g * 16) = v[g];
     }
+    if (tid < 256) sXq[tid] = requotient_c((float)(tid - 128), rcp_prepare(p.s_softmax));
     __syncthreads();
     if (tid < 64) {  // column sums of V (per d) over all keys
         int s = 0;
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void attn_fused_kernel(AttnArgs p) 
         v4i qf = {0, 0, 0, 0};
         if (q0 + qi < T) qf = *reinterpret_cast<const v4i *>(qg + (q0 + qi) * 64 + g * 16);
 
-        // ---- S^T tiles -> requant -> float(Q); running integer max
+        // ---- S^T tiles -> requant -> x~ = fl(fl(Q*s)/s) by table; running integer max
         float f[C::NT][4];
         int qmax = -128;
 #pragma unroll
@@ -126,10 +128,9 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void attn_fused_kernel(AttnArgs p) 
                 acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(kf, qf, acc, 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    int t = j * 16 + g * 4 + r;
                     int v = rq_c((double)acc[r], c_qk, -128, 127);
-                    f[j][r] = (float)v;
-                    if (t < T) qmax = max(qmax, v);
+                    f[j][r] = sXq[v + 128];
+                    if (j * 16 + 15 < T || j * 16 + g * 4 + r < T) qmax = max(qmax, v);
                 }
             } else {
 #pragma unroll
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void attn_fused_kernel(AttnArgs p) 
         }
         qmax = max(qmax, __shfl_xor(qmax, 16));
         qmax = max(qmax, __shfl_xor(qmax, 32));
-        const float mx = requotient_c((float)qmax, sr);
+        const float mx = sXq[qmax + 128];
 
         // ---- shift-exp; keys >= T contribute exactly 0
 #pragma unroll
@@ -146,9 +147,8 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void attn_fused_kernel(AttnArgs p) 
             if (j < ntile) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    int t = j * 16 + g * 4 + r;
-                    float e = shift_exp_c(requotient_c(f[j][r], sr) - mx, x0r, nx0, 15);
-                    f[j][r] = t < T ? e : 0.f;
+                    float e = shift_exp_f(f[j][r] - mx, x0r, nx0, 15);
+                    f[j][r] = (j * 16 + 15 < T || j * 16 + g * 4 + r < T) ? e : 0.f;
                 }
             }
         }
@@ -229,26 +229,24 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void attn_fused_kernel(AttnArgs p) 
         }
         const float F = recip_factor(fin);
 
-        // ---- probabilities -> (hi, lo) int8 planes, packed as P·V A fragments
-        v4i plo[NB], phi[NB];
+        // ---- probabilities -> (hi, lo) int8 planes, packed as P·V A fragments.
+        // P - 16384 = 256*hi + lo (lo signed)  <=>  lo = byte0(P), hi = byte1(P - 16256)
+        const float F16 = F * 1.52587890625e-05f;     // F / 2**16: exact scaling, so
+        v4i plo[NB], phi[NB];                         // fl(e*F16) == fl(e*F) / 2**16
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 const int j = kb * 4 + jj;
-                unsigned wl = 0, wh = 0;
+                unsigned wl = 0, wh = 0xC0C0C0C0u;   // P = 0 -> hi = -64, lo = 0 (V is 0 there)
                 if (j < ntile) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        int P = (int)floorf((f[j][r] * F) * 1.52587890625e-05f);  // / 2**16
-                        int a = P - 16384;
-                        int l8 = (int)(int8_t)(a & 0xff);
-                        int h8 = (a - l8) >> 8;
-                        wl |= (unsigned)(l8 & 0xff) << (8 * r);
-                        wh |= (unsigned)(h8 & 0xff) << (8 * r);
-                    }
-                } else {
-                    wh = 0xC0C0C0C0u;  // P = 0 -> a = -16384 -> hi = -64, lo = 0 (V is 0 there)
+                    unsigned P0 = (unsigned)(int)floorf(f[j][0] * F16), P1 = (unsigned)(int)floorf(f[j][1] * F16);
+                    unsigned P2 = (unsigned)(int)floorf(f[j][2] * F16), P3 = (unsigned)(int)floorf(f[j][3] * F16);
+                    unsigned l01 = __builtin_amdgcn_perm(P1, P0, 0x0c0c0400u), l23 = __builtin_amdgcn_perm(P3, P2, 0x0c0c0400u);
+                    wl = __builtin_amdgcn_perm(l23, l01, 0x05040100u);
+                    unsigned h01 = __builtin_amdgcn_perm(P1 - 16256u, P0 - 16256u, 0x0c0c0501u);
+                    unsigned h23 = __builtin_amdgcn_perm(P3 - 16256u, P2 - 16256u, 0x0c0c0501u);
+                    wh = __builtin_amdgcn_perm(h23, h01, 0x05040100u);
                 }
                 plo[kb][jj] = (int)wl;
                 phi[kb][jj] = (int)wh;

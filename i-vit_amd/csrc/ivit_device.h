@@ -84,6 +84,20 @@ __device__ __forceinline__ float shift_exp_c(float x, RcpC x0, float nx0, int n)
     return fmaxf(e, 0.0f);
 }
 
+// shift_exp on a precomputed x (same value sequence as shift_exp_c; the two products
+// x0*q and r*0.5 are exact, so fma(-x0,q,t) == fl(t - fl(x0*q)) and fma(r,0.5,-x0) ==
+// fl(fl(r/2) - x0) bit for bit)
+__device__ __forceinline__ float shift_exp_f(float x, RcpC x0, float nx0, int n) {
+    float t = x + floorf(x * 0.5f);
+    t = t - floorf(x * 0.0625f);
+    t = fmaxf(t, nx0);
+    float q = floorf(lean_div(t, x0));
+    float r = __builtin_fmaf(-x0.d, q, t);
+    float e = __builtin_fmaf(r, 0.5f, -x0.d);
+    e = floorf(ldexpf(e, n - (int)q));
+    return fmaxf(e, 0.0f);
+}
+
 // ---- fp32-faithful pieces ---------------------------------------------------
 // value a consumer of (Q, s) sees: fl(fl(Q*s)/s)   (quant_modules.py:204-206 then
 // :94/:359/:426/:484).  Not always equal to Q.
