@@ -170,3 +170,42 @@ __device__ __forceinline__ float torch_order_sum32(int n, int sub, F elem) {
     }
     return fin;
 }
+
+// Same summation order with 16 lanes per row (sub in [0,16)): lane `sub` owns the two
+// accumulators sub and sub+16.  Every one of the 16 lanes returns the full sum.
+template <typename F>
+__device__ __forceinline__ float torch_order_sum16(int n, int sub, F elem) {
+    const int nvec = n >> 3, size = nvec >> 2;
+    float a0[2] = {0.f, 0.f}, a1[2] = {0.f, 0.f}, a2[2] = {0.f, 0.f}, a3[2] = {0.f, 0.f};
+    int i = 0;
+    for (; i + 16 <= size;) {
+        for (int j = 0; j < 16; ++j, ++i) {
+            a0[0] += elem(32 * i + sub);
+            a0[1] += elem(32 * i + sub + 16);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { a1[s] += a0[s]; a0[s] = 0.f; }
+        if ((i & 0xF0) != 0) continue;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { a2[s] += a1[s]; a1[s] = 0.f; }
+        if ((i & 0xF00) != 0) continue;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { a3[s] += a2[s]; a2[s] = 0.f; }
+    }
+    for (; i < size; ++i) {
+        a0[0] += elem(32 * i + sub);
+        a0[1] += elem(32 * i + sub + 16);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) { a0[s] += a1[s]; a0[s] += a2[s]; a0[s] += a3[s]; }
+    for (int v = size * 4; v < nvec; ++v) a0[0] += (sub < 8) ? elem(v * 8 + sub) : 0.f;
+    const float o0 = __shfl(a0[0], (sub & 7) + 8, 16), o1 = __shfl(a0[1], (sub & 7) + 8, 16);
+    const float p = ((a0[0] + o0) + a0[1]) + o1;       // valid on lanes sub < 8
+    float fin = 0.f;
+    for (int k = nvec * 8; k < n; ++k) fin += elem(k);
+    if (nvec > 0) {
+#pragma unroll
+        for (int l = 0; l < 8; ++l) fin += __shfl(p, l, 16);
+    }
+    return fin;
+}

@@ -158,6 +158,99 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const int16_t *__restric
 }
 
 // ---------------------------------------------------------------------------
+// a7 + a3, production form.  16 lanes per row (4 rows per wavefront, 16 per 256-thread block,
+// LN_RITER row groups per block): per-channel constants — sc, its refined reciprocal, bias_int
+// and the requant multiplier c = m*2^-e — are staged once per block in LDS; the integer Newton
+// iteration leaves its loop as soon as every row of the wavefront sits on a fixed point
+// (k' == k implies all later iterates equal k, so the early exit is exact).
+#define LN_RITER 4
+__global__ __launch_bounds__(256) void layernorm16_kernel(const int16_t *__restrict__ x, long long rows, int C,
+                                                          long long row_stride, float s,
+                                                          const float *__restrict__ bias_int,
+                                                          const float *__restrict__ sc,
+                                                          const ivit_dyadic *__restrict__ dy,
+                                                          int8_t *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char dsmem[];
+    const int LD = C + 16;                                   // row stride (floats): skews rows by 16 banks
+    float *xrows = reinterpret_cast<float *>(dsmem);          // [16][LD]
+    double *cC = reinterpret_cast<double *>(dsmem + (size_t)16 * LD * 4);   // [C]
+    float *cSc = reinterpret_cast<float *>(cC + C);            // [C]
+    float *cY = cSc + C;                                       // [C]
+    float *cB = cY + C;                                        // [C]
+    const int tid = threadIdx.x;
+    for (int c = tid; c < C; c += 256) {
+        const float scv = sc[c];
+        cSc[c] = scv;
+        cY[c] = rcp_prepare(scv).y;
+        cB[c] = bias_int[c];
+        cC[c] = dy[c].m * dy[c].r;
+    }
+    __syncthreads();
+    const int sub = tid & 15, slot = tid >> 4;
+    float *xr = xrows + (size_t)slot * LD;
+    const RcpC sr = rcp_prepare(s);
+    const float Cf = (float)C;
+    const int nch8 = C >> 3;
+    for (int it = 0; it < LN_RITER; ++it) {
+        const long long row_raw = ((long long)blockIdx.x * LN_RITER + it) * 16 + slot;
+        const bool live = row_raw < rows;
+        const long long row = live ? row_raw : rows - 1;     // dead groups recompute the last row, store nothing
+        const int16_t *xp = x + row * row_stride;
+        for (int c = sub; c < nch8; c += 16) {
+            v8s q = *reinterpret_cast<const v8s *>(xp + c * 8);
+            v4f lo, hi;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                lo[e] = requotient_c((float)q[e], sr);
+                hi[e] = requotient_c((float)q[4 + e], sr);
+            }
+            *reinterpret_cast<v4f *>(xr + c * 8) = lo;
+            *reinterpret_cast<v4f *>(xr + c * 8 + 4) = hi;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const float sum = torch_order_sum16(C, sub, [&](int idx) { return xr[idx]; });
+        const float mean = rintf(sum / Cf);
+        const float var = torch_order_sum16(C, sub, [&](int idx) {
+            float y = xr[idx] - mean;
+            return y * y;
+        });
+        float k = 65536.0f;
+        for (int n = 0; n < 10; ++n) {
+            const float kn = floorf((k + floorf(var / k)) * 0.5f);
+            const bool same = (kn == k);
+            k = kn;
+            if (__all(same)) break;
+        }
+        const float F = floorf((1.0f / k) * 2147483648.0f);
+        for (int c = sub; c < nch8; c += 16) {
+            const v4f a = *reinterpret_cast<const v4f *>(xr + c * 8), b = *reinterpret_cast<const v4f *>(xr + c * 8 + 4);
+            const v4f bi0 = *reinterpret_cast<const v4f *>(cB + c * 8), bi1 = *reinterpret_cast<const v4f *>(cB + c * 8 + 4);
+            const v4f sc0 = *reinterpret_cast<const v4f *>(cSc + c * 8), sc1 = *reinterpret_cast<const v4f *>(cSc + c * 8 + 4);
+            const v4f y0 = *reinterpret_cast<const v4f *>(cY + c * 8), y1 = *reinterpret_cast<const v4f *>(cY + c * 8 + 4);
+            unsigned pk[2] = {0, 0};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xv = e < 4 ? a[e] : b[e - 4];
+                const float bi = e < 4 ? bi0[e] : bi1[e - 4];
+                RcpC rc;
+                rc.d = e < 4 ? sc0[e] : sc1[e - 4];
+                rc.y = e < 4 ? y0[e] : y1[e - 4];
+                const float y = xv - mean;
+                const float yi = floorf((y * F) * 0.5f);
+                const float o = yi + bi;
+                const float zz = rintf(lean_div(o * rc.d, rc));
+                const int v = rq_c((double)zz, cC[c * 8 + e], -128, 127);
+                pk[e >> 2] |= ((unsigned)v & 0xffu) << (8 * (e & 3));
+            }
+            if (live) *reinterpret_cast<v2i *>(out + row * C + c * 8) = v2i{(int)pk[0], (int)pk[1]};
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+}
+
+// ---------------------------------------------------------------------------
 // a5: Shiftmax (quant_modules.py:469-497).  One wavefront per row; the row's exp
 // values are staged in LDS (fp32) for the torch-order sum done by lanes 0..31.
 __global__ __launch_bounds__(256) void shiftmax_kernel(const int8_t *__restrict__ x, long long rows, int n,

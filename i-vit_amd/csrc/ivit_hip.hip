@@ -380,6 +380,20 @@ int ivit_layernorm_requant(ivit_handle h, const int16_t *x, int64_t rows, int C,
     CHECK_H(h);
     REQUIRE(h, x && bias_int && sc && dy_ch && out8 && rows > 0 && C > 0 && scale > 0.f, "bad arguments");
     REQUIRE(h, (C % 8) == 0 && (row_stride % 8) == 0 && row_stride >= C, "C, row_stride multiples of 8");
+    {   // production form: 16 lanes per row, constants staged in LDS
+        const size_t lds16 = (size_t)16 * (C + 16) * 4 + (size_t)C * 20;
+        static int ln_old = -1;
+        if (ln_old < 0) { const char *e = getenv("IVIT_LN_OLD"); ln_old = e ? atoi(e) : 0; }
+        if (lds16 <= 150 * 1024 && !ln_old) {
+            int st16 = set_dyn_lds(h, (const void *)layernorm16_kernel, lds16);
+            if (st16) return st16;
+            const long long per_block = 16 * LN_RITER;
+            layernorm16_kernel<<<(unsigned)((rows + per_block - 1) / per_block), 256, lds16, h->stream>>>(
+                x, rows, C, row_stride, scale, bias_int, sc, dy_ch, out8);
+            LAUNCH_CHECK(h);
+            return IVIT_OK;
+        }
+    }
     const size_t lds = (size_t)8 * C * sizeof(float);
     REQUIRE(h, lds <= 160 * 1024, "C too large for LDS staging");
     int st = set_dyn_lds(h, (const void *)layernorm_kernel<true>, lds);
