@@ -204,15 +204,17 @@ __global__ __launch_bounds__(256) void layernorm16_kernel(const int16_t *__restr
                 lo[e] = requotient_c((float)q[e], sr);
                 hi[e] = requotient_c((float)q[4 + e], sr);
             }
-            *reinterpret_cast<v4f *>(xr + c * 8) = lo;
-            *reinterpret_cast<v4f *>(xr + c * 8 + 4) = hi;
+            const int pc = (c * 8) ^ (((c >> 2) & 3) << 3);   // bank swizzle: rotate 8-float groups by row
+            *reinterpret_cast<v4f *>(xr + pc) = lo;
+            *reinterpret_cast<v4f *>(xr + pc + 4) = hi;
         }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        const float sum = torch_order_sum16(C, sub, [&](int idx) { return xr[idx]; });
+        auto xat = [&](int idx) { return xr[idx ^ (((idx >> 5) & 3) << 3)]; };
+        const float sum = torch_order_sum16(C, sub, xat);
         const float mean = rintf(sum / Cf);
         const float var = torch_order_sum16(C, sub, [&](int idx) {
-            float y = xr[idx] - mean;
+            float y = xat(idx) - mean;
             return y * y;
         });
         float k = 65536.0f;
@@ -224,7 +226,8 @@ __global__ __launch_bounds__(256) void layernorm16_kernel(const int16_t *__restr
         }
         const float F = floorf((1.0f / k) * 2147483648.0f);
         for (int c = sub; c < nch8; c += 16) {
-            const v4f a = *reinterpret_cast<const v4f *>(xr + c * 8), b = *reinterpret_cast<const v4f *>(xr + c * 8 + 4);
+            const int pc = (c * 8) ^ (((c >> 2) & 3) << 3);
+            const v4f a = *reinterpret_cast<const v4f *>(xr + pc), b = *reinterpret_cast<const v4f *>(xr + pc + 4);
             const v4f bi0 = *reinterpret_cast<const v4f *>(cB + c * 8), bi1 = *reinterpret_cast<const v4f *>(cB + c * 8 + 4);
             const v4f sc0 = *reinterpret_cast<const v4f *>(cSc + c * 8), sc1 = *reinterpret_cast<const v4f *>(cSc + c * 8 + 4);
             const v4f y0 = *reinterpret_cast<const v4f *>(cY + c * 8), y1 = *reinterpret_cast<const v4f *>(cY + c * 8 + 4);
