@@ -302,7 +302,7 @@ def _engine_for(g):
 
 
 @pytest.mark.parametrize("fname", ["micro_vit_b2.npz", "micro_vit2h_b3.npz", "deit_tiny_b1.npz",
-                                   "deit_small_b4.npz"])
+                                   "deit_small_b4.npz", "deit_base_b2.npz", "vit_base_384_b1.npz"])
 def test_vit_forward_golden_logits(fname):
     g = load_golden(fname)
     cfg, w, eng = _engine_for(g)

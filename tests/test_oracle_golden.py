@@ -90,7 +90,7 @@ def test_micro_model_every_site(fname):
     assert np.array_equal(s_head, g["logits_scale"])
 
 
-@pytest.mark.parametrize("fname", ["deit_tiny_b1.npz", "deit_small_b4.npz"])
+@pytest.mark.parametrize("fname", ["deit_tiny_b1.npz", "deit_small_b4.npz", "deit_base_b2.npz"])
 def test_deit_logits_and_site_checksums(fname):
     g = load_golden(fname)
     cfg = iv.CONFIGS[str(g["cfg_name"])]

@@ -246,6 +246,8 @@ def main():
     model_fixture(models, "micro_vit2h", 3, 4, 0, True, "micro_vit2h_b3.npz")
     model_fixture(models, "deit_tiny", 1, 2, 0, False, "deit_tiny_b1.npz")
     model_fixture(models, "deit_small", 4, 4, 0, False, "deit_small_b4.npz")
+    model_fixture(models, "deit_base", 2, 2, 0, False, "deit_base_b2.npz")
+    model_fixture(models, "vit_base_384", 1, 1, 0, False, "vit_base_384_b1.npz")
 
 
 if __name__ == "__main__":
