@@ -1,6 +1,7 @@
 """ivit_amd — MI355X-native integer-only ViT inference path (drop-in for the
 operator surface of zkkli/I-ViT models/quantization_utils + models/layers_quant.py)."""
-from .synth import ViTConfig, CONFIGS, make_vit_weights, make_images_int8, make_calibration_batch  # noqa
+from .synth import (ViTConfig, CONFIGS, make_vit_weights, make_images_int8, make_calibration_batch,  # noqa
+                    SwinConfig, SWIN_CONFIGS, make_swin_weights)
 from . import freeze  # noqa
 from . import _lib  # noqa
 from ._lib import IvitError, build  # noqa

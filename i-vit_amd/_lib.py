@@ -9,7 +9,7 @@ import subprocess
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 SO_PATH = os.path.join(_CSRC, "libivit_hip.so")
-SOURCES = ["ivit_hip.hip", "ivit_device.h", "ivit_gemm.h", "ivit_elementwise.h", "ivit_attention.h"]
+SOURCES = ["ivit_hip.hip", "ivit_device.h", "ivit_gemm.h", "ivit_elementwise.h", "ivit_attention.h", "ivit_gemm2.h", "ivit_swin.h"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
 
@@ -66,6 +66,10 @@ SIGNATURES = {
     "ivit_shiftgelu_requant_lut": [_P, _P, _L, _I, _P, _P],
     "ivit_layernorm": [_P, _P, _L, _I, _F, _P, _P, _P],
     "ivit_layernorm_requant": [_P, _P, _L, _I, _L, _F, _P, _P, _P, _P],
+    "ivit_shiftmax_masked": [_P, _P, _L, _I, _I, _F, _I, _P, _I, _I, _P, _I],
+    "ivit_requant_i32_bcast": [_P, _P, Dyadic, _P, _L, Dyadic, _I, _P, _L],
+    "ivit_avgpool_requant": [_P, _P, _I, _I, _I, Dyadic, _P],
+    "ivit_layernorm_tokenorder": [_P, _P, _L, _I, _F, _P, _P, _I, _P],
     "ivit_debug_div": [_P, _P, _P, _P, _P, _L],
     "ivit_im2col_patch": [_P, _P, _I, _I, _I, _I, _I, _P],
     "ivit_embed_finish": [_P, _P, _P, _P, Dyadic, Dyadic, _P, _I, _I, _I],

@@ -9,6 +9,7 @@
 #include "ivit_gemm.h"
 #include "ivit_attention.h"
 #include "ivit_gemm2.h"
+#include "ivit_swin.h"
 
 struct ivit_ctx {
     int device;
@@ -399,6 +400,58 @@ int ivit_layernorm_requant(ivit_handle h, const int16_t *x, int64_t rows, int C,
     int st = set_dyn_lds(h, (const void *)layernorm_kernel<true>, lds);
     if (st) return st;
     layernorm_kernel<true><<<(unsigned)((rows + 7) / 8), 256, lds, h->stream>>>(x, rows, C, row_stride, scale, bias_int, sc, dy_ch, out8);
+    LAUNCH_CHECK(h);
+    return IVIT_OK;
+}
+
+// ---------------------------------------------------------------- Swin-specific operators
+int ivit_shiftmax_masked(ivit_handle h, const int8_t *x, int64_t rows, int n, int ld_in, float scale, int out_bits,
+                         const float *mask, int nW, int H, uint16_t *out, int ld_out) {
+    CHECK_H(h);
+    REQUIRE(h, x && out && rows > 0 && n > 0 && ld_in >= n && ld_out >= n && scale > 0.f, "bad arguments");
+    REQUIRE(h, out_bits == 8 || out_bits == 16, "out_bits must be 8 or 16");
+    REQUIRE(h, mask == nullptr || (nW > 0 && H > 0), "mask needs nW, H");
+    const size_t lds = (size_t)4 * n * sizeof(float);
+    REQUIRE(h, lds <= 160 * 1024, "row too long for LDS staging");
+    int st = set_dyn_lds(h, (const void *)shiftmax_masked_kernel, lds);
+    if (st) return st;
+    shiftmax_masked_kernel<<<(unsigned)((rows + 3) / 4), 256, lds, h->stream>>>(x, rows, n, ld_in, scale, out_bits, mask,
+                                                                          nW > 0 ? nW : 1, H > 0 ? H : 1, out, ld_out);
+    LAUNCH_CHECK(h);
+    return IVIT_OK;
+}
+
+int ivit_requant_i32_bcast(ivit_handle h, const int32_t *z, ivit_dyadic dy, const int32_t *z_id, int64_t id_period,
+                           ivit_dyadic dy_id, int bits, void *out, int64_t total) {
+    CHECK_H(h);
+    REQUIRE(h, z && z_id && out && total > 0 && id_period > 0, "bad arguments");
+    REQUIRE(h, bits == 8 || bits == 16, "bits must be 8 or 16");
+    const int g = grid_for(h, total, 256 * 4);
+    if (bits == 8) requant_bcast_kernel<8><<<g, 256, 0, h->stream>>>(z, dy, z_id, id_period, dy_id, out, total);
+    else requant_bcast_kernel<16><<<g, 256, 0, h->stream>>>(z, dy, z_id, id_period, dy_id, out, total);
+    LAUNCH_CHECK(h);
+    return IVIT_OK;
+}
+
+int ivit_avgpool_requant(ivit_handle h, const int8_t *x, int B, int L, int C, ivit_dyadic dy, int8_t *out8) {
+    CHECK_H(h);
+    REQUIRE(h, x && out8 && B > 0 && L > 0 && C > 0, "bad arguments");
+    REQUIRE(h, (L & 1) == 1, "token count must be odd (no rounding ties; see kernel comment)");
+    avgpool_requant_kernel<<<(unsigned)((B * C + 255) / 256), 256, 0, h->stream>>>(x, B, L, C, dy, out8);
+    LAUNCH_CHECK(h);
+    return IVIT_OK;
+}
+
+int ivit_layernorm_tokenorder(ivit_handle h, const int16_t *x, int64_t rows, int C, float scale,
+                              const float *bias_int, const float *sc, int tokens_per_image, float *z) {
+    CHECK_H(h);
+    REQUIRE(h, x && bias_int && sc && z && rows > 0 && C > 0 && scale > 0.f && tokens_per_image > 0, "bad arguments");
+    const size_t lds = (size_t)64 * (C + 1) * sizeof(float);
+    REQUIRE(h, lds <= 160 * 1024, "C too large for LDS staging");
+    int st = set_dyn_lds(h, (const void *)layernorm_tokenorder_kernel<false>, lds);
+    if (st) return st;
+    layernorm_tokenorder_kernel<false><<<(unsigned)((rows + 63) / 64), 64, lds, h->stream>>>(
+        x, rows, C, scale, bias_int, sc, nullptr, tokens_per_image, z);
     LAUNCH_CHECK(h);
     return IVIT_OK;
 }

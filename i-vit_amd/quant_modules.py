@@ -54,6 +54,14 @@ def _dyv(d):
     return _lib.Dyadic(float(d[0, 0]), float(d[0, 1]))
 
 
+def _leading_broadcast(id_shape, x_shape):
+    """True if `identity` broadcasts to x only over leading dims (trailing dims identical)."""
+    id_shape = tuple(id_shape)
+    while id_shape and id_shape[0] == 1:
+        id_shape = id_shape[1:]
+    return len(id_shape) <= len(x_shape) and tuple(x_shape[len(x_shape) - len(id_shape):]) == id_shape
+
+
 def to_int(x_fp32, scale, dtype=torch.int32):
     """integer view of a reference-style fake-quant tensor: rne(x / s) (quant_utils.py:220)"""
     s = torch.as_tensor(_f32(scale), device=x_fp32.device)
@@ -198,7 +206,15 @@ class QuantAct(nn.Module):
             s_id = _f32(identity_scaling_factor)
             if s_id.size != 1:
                 raise NotImplementedError("identity scale must be per-tensor")
-            _, di = self._dy.get(s_id, s_out, x.device)
+            di_host, di = self._dy.get(s_id, s_out, x.device)
+            if (identity.numel() < x.numel() and s_pre.size == 1 and x.dtype != torch.float32
+                    and bits in (8, 16) and _leading_broadcast(identity.shape, x.shape)):
+                zc = x.to(torch.int32).contiguous()
+                idc = identity.to(torch.int32).contiguous()
+                out = torch.empty(x.shape, dtype=out_dt, device=x.device)
+                h.call("ivit_requant_i32_bcast", _ptr(zc), _dyv(d), _ptr(idc), idc.numel(), _dyv(di_host), bits,
+                       _ptr(out), zc.numel())
+                return out, self.act_scaling_factor
             zi = identity.to(torch.int32).expand(x.shape).contiguous()
         out = torch.empty(x.shape, dtype=out_dt, device=x.device)
         rows = x.numel() // C
@@ -316,6 +332,10 @@ class IntLayerNorm(nn.LayerNorm):
         self.register_buffer("norm_scaling_factor", torch.zeros(1))
         self.register_buffer("bias_integer", torch.zeros_like(self.bias))
         self._frozen = None
+        # The reference's two row sums follow torch's summation order, which depends on the MEMORY
+        # LAYOUT of its fp32 activation: "channel" (contiguous last dim, the usual case) or "token"
+        # (Swin stage 0, where activations keep the layout of flatten(2).transpose(1,2)).
+        self.sum_order = "channel"
 
     def fix(self):
         pass
@@ -336,7 +356,12 @@ class IntLayerNorm(nn.LayerNorm):
         C = x.shape[-1]
         xc = x.to(torch.int16).contiguous()
         z = torch.empty(x.shape, dtype=torch.float32, device=x.device)
-        handle(x.device).call("ivit_layernorm", _ptr(xc), xc.numel() // C, C, float(s), _ptr(bi_d), _ptr(sc_d), _ptr(z))
+        if self.sum_order == "token":
+            handle(x.device).call("ivit_layernorm_tokenorder", _ptr(xc), xc.numel() // C, C, float(s), _ptr(bi_d),
+                                  _ptr(sc_d), int(x.shape[-2]), _ptr(z))
+        else:
+            handle(x.device).call("ivit_layernorm", _ptr(xc), xc.numel() // C, C, float(s), _ptr(bi_d), _ptr(sc_d),
+                                  _ptr(z))
         return z, torch.from_numpy(sc)
 
 
@@ -385,12 +410,19 @@ class IntSoftmax(nn.Module):
     def unfix(self):
         pass
 
-    def forward(self, x, scaling_factor):
+    def forward(self, x, scaling_factor, mask=None, num_heads=1):
+        """mask: optional float [nW, n, n] (0 / -100.0) — the reference adds it to the fp32 logits
+        right before this module (swin_quant.py:151-156); with integer activations it is passed in."""
         s = np.float32(_f32(scaling_factor)[0])
         n = x.shape[-1]
         xc = x.contiguous()
         out = torch.empty(x.shape, dtype=torch.int16, device=x.device)    # uint16 payload
-        handle(x.device).call("ivit_shiftmax", _ptr(xc), xc.numel() // n, n, n, float(s), self.output_bit,
-                              _ptr(out), n)
+        if mask is not None:
+            mk = mask.to(device=x.device, dtype=torch.float32).contiguous()
+            handle(x.device).call("ivit_shiftmax_masked", _ptr(xc), xc.numel() // n, n, n, float(s), self.output_bit,
+                                  _ptr(mk), int(mk.shape[0]), int(num_heads), _ptr(out), n)
+        else:
+            handle(x.device).call("ivit_shiftmax", _ptr(xc), xc.numel() // n, n, n, float(s), self.output_bit,
+                                  _ptr(out), n)
         self.act_scaling_factor = torch.tensor([1.0 / 2 ** (self.output_bit - 1)])
         return out.to(torch.int32) & 0xFFFF, self.act_scaling_factor

@@ -111,3 +111,83 @@ def make_calibration_batch(cfg: ViTConfig, batch: int, seed: int = 2):
     """Seeded fp32 batch used for the single calibration forward (values in ~N(0,1))."""
     rng = np.random.Generator(np.random.PCG64(seed))
     return rng.standard_normal((batch, cfg.in_chans, cfg.img_size, cfg.img_size)).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------
+# Swin (reference models/swin_quant.py:419-627)
+@dataclass(frozen=True)
+class SwinConfig:
+    name: str
+    img_size: int = 224
+    patch_size: int = 4
+    in_chans: int = 3
+    num_classes: int = 1000
+    embed_dim: int = 96
+    depths: tuple = (2, 2, 6, 2)
+    num_heads: tuple = (3, 6, 12, 24)
+    window_size: int = 7
+    mlp_ratio: int = 4
+
+    @property
+    def grid(self):
+        return self.img_size // self.patch_size
+
+    @property
+    def num_layers(self):
+        return len(self.depths)
+
+    @property
+    def num_features(self):
+        return self.embed_dim * 2 ** (self.num_layers - 1)
+
+    def to_dict(self):
+        return asdict(self)
+
+
+SWIN_CONFIGS = {
+    "micro_swin": SwinConfig("micro_swin", img_size=56, num_classes=10, embed_dim=32, depths=(2, 2),
+                             num_heads=(1, 2)),
+    "swin_tiny": SwinConfig("swin_tiny"),
+    "swin_small": SwinConfig("swin_small", depths=(2, 2, 18, 2)),
+    "swin_base": SwinConfig("swin_base", embed_dim=128, depths=(2, 2, 18, 2), num_heads=(4, 8, 16, 32)),
+}
+
+
+def make_swin_weights(cfg: SwinConfig, seed: int = 0):
+    """Float32 parameters of a Swin model keyed like the reference state dict."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    w = {}
+    P, E = cfg.patch_size, cfg.embed_dim
+
+    def ln(prefix, C):
+        w[prefix + ".weight"] = (1.0 + rng.standard_normal(C) * 0.4).astype(np.float32)
+        w[prefix + ".bias"] = (rng.standard_normal(C) * 0.5).astype(np.float32)
+
+    def lin(prefix, out_f, in_f, gain, bias=True):
+        w[prefix + ".weight"] = _tn(rng, (out_f, in_f), 0.02, gain)
+        if bias:
+            w[prefix + ".bias"] = (rng.standard_normal(out_f) * 0.3).astype(np.float32)
+
+    w["patch_embed.proj.weight"] = _tn(rng, (E, cfg.in_chans, P, P), 0.02, 6.0)
+    w["patch_embed.proj.bias"] = (rng.standard_normal(E) * 0.3).astype(np.float32)
+    ln("patch_embed.norm", E)
+    ws = cfg.window_size
+    for i, (depth, heads) in enumerate(zip(cfg.depths, cfg.num_heads)):
+        C = E * 2 ** i
+        res = cfg.grid // 2 ** i
+        for j in range(depth):
+            b = f"layers.{i}.blocks.{j}."
+            ln(b + "norm1", C)
+            wsz = min(ws, res)
+            w[b + "attn.relative_position_bias_table"] = _tn(rng, ((2 * wsz - 1) ** 2, heads), 0.02, 20.0)
+            lin(b + "attn.qkv", 3 * C, C, 6.0)
+            lin(b + "attn.proj", C, C, 2.0)
+            ln(b + "norm2", C)
+            lin(b + "mlp.fc1", C * cfg.mlp_ratio, C, 2.0)
+            lin(b + "mlp.fc2", C, C * cfg.mlp_ratio, 2.0)
+        if i < cfg.num_layers - 1:
+            ln(f"layers.{i}.downsample.norm", 4 * C)
+            lin(f"layers.{i}.downsample.reduction", 2 * C, 4 * C, 2.0, bias=False)
+    ln("norm", cfg.num_features)
+    lin("head", cfg.num_classes, cfg.num_features, 2.0)
+    return w

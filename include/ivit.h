@@ -175,6 +175,26 @@ int ivit_embed_finish(ivit_handle h, const int16_t *patch16, const int32_t *z_cl
                       const int16_t *pos, ivit_dyadic dy_x, ivit_dyadic dy_pos, int16_t *x16,
                       int B, int T, int D);
 
+/* ---- a12  Swin-specific operators (models/swin_quant.py)
+ * IntSoftmax on `attn + mask` (:151-156): float mask [nW, n, n] (0 / -100.0) added to fl(Q*s)
+ * before the division by s; row r of the flattened [B_, H, n] rows uses window (r/(H*n)) % nW.
+ * mask == NULL: identical to ivit_shiftmax.                                                */
+int ivit_shiftmax_masked(ivit_handle h, const int8_t *x, int64_t rows, int n, int ld_in, float scale,
+                         int out_bits, const float *mask, int nW, int H, uint16_t *out, int ld_out);
+/* QuantAct with an identity that repeats every id_period elements (relative position bias
+ * [H,N,N] broadcast over windows, :149): out = clamp(rq(z[i],dy) + rq(z_id[i % period],dy_id)) */
+int ivit_requant_i32_bcast(ivit_handle h, const int32_t *z, ivit_dyadic dy, const int32_t *z_id,
+                           int64_t id_period, ivit_dyadic dy_id, int bits, void *out, int64_t total);
+/* AdaptiveAvgPool1d(1) over L (odd) tokens + QuantAct(8) (:553-555): x int8 [B,L,C] -> [B,C]   */
+int ivit_avgpool_requant(ivit_handle h, const int8_t *x, int B, int L, int C, ivit_dyadic dy,
+                         int8_t *out8);
+/* IntLayerNorm whose row sums follow torch's order for a TOKEN-contiguous input — what the
+ * reference computes in Swin stage 0, where activations keep the layout of
+ * flatten(2).transpose(1,2) (layers_quant.py:188).  Same outputs as
+ * ivit_layernorm otherwise.                                                                */
+int ivit_layernorm_tokenorder(ivit_handle h, const int16_t *x, int64_t rows, int C, float scale,
+                              const float *bias_int, const float *sc, int tokens_per_image, float *z);
+
 /* ---- diagnostics (used by the parity tests only) ------------------------------------
  * q_ieee = n / d (compiler's correctly-rounded division) and q_lean = the hoisted-reciprocal
  * FMA sequence the kernels use for constant divisors; must agree bit for bit.            */

@@ -300,6 +300,81 @@ void ivit_ref_layernorm(const int16_t *x, int64_t rows, int64_t C, float s, cons
     }
 }
 
+/* torch-CPU `sum` over a NON-contiguous last dim whose neighbouring dim (tokens) is the
+ * contiguous one — what the reference's IntLayerNorm sees in Swin stage 0, where the
+ * activation keeps the layout of `x.flatten(2).transpose(1, 2)` (layers_quant.py:188,
+ * swin_quant.py:251-258).  ATen SumKernel vectorized_outer_sum: tokens are processed in groups of
+ * 32 (4 x 8 lanes) with multi_row_sum over the channels = plain sequential accumulation with
+ * the 16-step cascade; the last (L mod 32) tokens of an image use row_sum = 4 interleaved
+ * accumulators.  parallel chunks are rounded to 32 tokens, so this is thread-count invariant
+ * whenever L % 32 == 0 (Swin-T: L = 3136).                                              */
+static float cascade_seq_sum(const float *x, int64_t n, int64_t stride) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int level_power = ceil_log2_i64(n) / 4;
+    if (level_power < 4) level_power = 4;
+    const int64_t step = (int64_t)1 << level_power, lmask = step - 1;
+    int64_t i = 0;
+    for (; i + step <= n;) {
+        for (int64_t j = 0; j < step; ++j, ++i) a0 += x[i * stride];
+        a1 += a0; a0 = 0.f;
+        if ((i & (lmask << level_power)) != 0) continue;
+        a2 += a1; a1 = 0.f;
+        if ((i & (lmask << (2 * level_power))) != 0) continue;
+        a3 += a2; a2 = 0.f;
+    }
+    for (; i < n; ++i) a0 += x[i * stride];
+    a0 += a1; a0 += a2; a0 += a3;
+    return a0;
+}
+float ivit_ref_torch_sum_strided_f32(const float *x, int64_t n, int ilp4) {
+    if (!ilp4) return cascade_seq_sum(x, n, 1);
+    const int64_t size_ilp = n / 4;
+    float ps[4];
+    for (int k = 0; k < 4; ++k) ps[k] = cascade_seq_sum(x + k, size_ilp, 4);
+    for (int64_t i = size_ilp * 4; i < n; ++i) ps[0] += x[i];
+    ps[0] += ps[1]; ps[0] += ps[2]; ps[0] += ps[3];
+    return ps[0];
+}
+
+/* I-LayerNorm with the summation order selected by the reference-side memory layout:
+ * order 0 = channel-contiguous input (ivit_ref_layernorm); order 1 = token-contiguous input,
+ * L tokens per image (see above).                                                       */
+void ivit_ref_layernorm_ord(const int16_t *x, int64_t rows, int64_t C, float s, const float *bias_int,
+                            const float *sc, float *z, int order, int64_t L) {
+#pragma omp parallel
+    {
+        float *xt = (float *)malloc(sizeof(float) * (size_t)C);
+        float *y2 = (float *)malloc(sizeof(float) * (size_t)C);
+#pragma omp for schedule(static)
+        for (int64_t i = 0; i < rows; ++i) {
+            const int16_t *xi = x + i * C;
+            const int ilp4 = order == 1 && (i % L) >= (L / 32) * 32;
+            for (int64_t j = 0; j < C; ++j) {
+                float X = (float)xi[j] * s;
+                xt[j] = X / s;
+            }
+            float sum = order == 0 ? ivit_ref_torch_sum_f32(xt, C) : ivit_ref_torch_sum_strided_f32(xt, C, ilp4);
+            float mean = rintf(sum / (float)C);
+            for (int64_t j = 0; j < C; ++j) {
+                xt[j] = xt[j] - mean;
+                y2[j] = xt[j] * xt[j];
+            }
+            float var = order == 0 ? ivit_ref_torch_sum_f32(y2, C) : ivit_ref_torch_sum_strided_f32(y2, C, ilp4);
+            float k = 65536.0f;
+            for (int it = 0; it < 10; ++it) k = floorf((k + floorf(var / k)) / 2.0f);
+            float F = floorf((1.0f / k) * 2147483648.0f);
+            for (int64_t j = 0; j < C; ++j) {
+                float yi = floorf((xt[j] * F) / 2.0f);
+                float o = yi + bias_int[j];
+                float Xo = o * sc[j];
+                z[i * C + j] = rintf(Xo / sc[j]);
+            }
+        }
+        free(xt);
+        free(y2);
+    }
+}
+
 /* a8: patch gather for QuantConv2d with kernel=stride=P (layers_quant.py:184-196,
  * quant_modules.py:297-330).  NCHW int8 image -> rows [B*gh*gw, Cin*P*P] in the
  * conv-weight element order (c, ph, pw), so conv == ivit_ref_linear_i8.          */
@@ -315,4 +390,55 @@ void ivit_ref_im2col_patch(const int8_t *img, int64_t B, int64_t Cin, int64_t H,
                         memcpy(o + (c * P + py) * P,
                                img + ((b * Cin + c) * H + gy * P + py) * W + gx * P, (size_t)P);
             }
+}
+
+/* ------------------------------------------------------------------------- */
+/* Swin: IntSoftmax fed by `attn + mask` (models/swin_quant.py:151-156): the float mask
+ * (0 / -100.0) is added to the fp32 logits fl(Q*s) BEFORE IntSoftmax divides by s, so masked
+ * inputs are non-integers.  Row r of the flattened [B_, H, n] rows uses mask[(r/(H*n)) % nW][r % n][:].
+ * mask == NULL reproduces ivit_ref_shiftmax.                                         */
+void ivit_ref_shiftmax_masked(const int8_t *x, int64_t rows, int64_t n, int64_t ld_in, float s,
+                              int out_bits, const float *mask, int64_t nW, int64_t H, uint16_t *out,
+                              int64_t ld_out) {
+    const float x0 = floorf(-1.0f / s);
+    const float nx0 = 15.0f * x0;
+    const float div = ldexpf(1.0f, 31 - out_bits + 1);
+#pragma omp parallel
+    {
+        float *xt = (float *)malloc(sizeof(float) * (size_t)n);
+        float *e = (float *)malloc(sizeof(float) * (size_t)n);
+#pragma omp for schedule(static)
+        for (int64_t i = 0; i < rows; ++i) {
+            const int8_t *xi = x + i * ld_in;
+            const float *mr = mask ? mask + (((i / (H * n)) % nW) * n + (i % n)) * n : NULL;
+            float mx = -INFINITY;
+            for (int64_t j = 0; j < n; ++j) {
+                float X = (float)xi[j] * s;
+                if (mr) X = X + mr[j];
+                xt[j] = X / s;
+                mx = xt[j] > mx ? xt[j] : mx;
+            }
+            for (int64_t j = 0; j < n; ++j) e[j] = iexp_shift(xt[j] - mx, x0, nx0, 15);
+            float S = ivit_ref_torch_sum_f32(e, n);
+            S = S < 2147483648.0f ? S : 2147483648.0f;
+            float F = floorf((1.0f / S) * 2147483648.0f);
+            uint16_t *o = out + i * ld_out;
+            for (int64_t j = 0; j < n; ++j) o[j] = (uint16_t)floorf((e[j] * F) / div);
+        }
+        free(xt);
+        free(e);
+    }
+}
+
+/* Swin head: AdaptiveAvgPool1d(1) over the L tokens of fl(Q*s) (swin_quant.py:554), fp32
+ * sequential sum then /L, followed by the next QuantAct's z = round(fl(mean/s))
+ * (quant_utils.py:220).  x int8 [B, L, C] -> z int32 [B, C].                          */
+void ivit_ref_avgpool_z(const int8_t *x, int64_t B, int64_t L, int64_t C, float s, int32_t *z) {
+    for (int64_t b = 0; b < B; ++b)
+        for (int64_t c = 0; c < C; ++c) {
+            float sum = 0.0f;
+            for (int64_t l = 0; l < L; ++l) sum += (float)x[(b * L + l) * C + c] * s;
+            float mean = sum / (float)L;
+            z[b * C + c] = (int32_t)rintf(mean / s);
+        }
 }

@@ -377,3 +377,33 @@ def test_operator_error_behaviour():
     act = iv.QuantAct()   # running_stat=True: calibration is not on the device path
     with pytest.raises(NotImplementedError):
         act(torch.zeros(4, 8, dtype=torch.int32, device="cuda"), torch.tensor(0.1))
+
+
+@pytest.mark.parametrize("fname", ["micro_swin_b2.npz", "swin_tiny_b1.npz"])
+def test_swin_operator_surface_golden(fname):
+    """Swin on the operator surface (windowed attention dh=32, 8-bit masked Shiftmax, rel-pos bias,
+    patch merging, avg-pool) reproduces the reference: every site (micro) / logits (Swin-T)."""
+    from ivit_amd.swin_quant import SwinTransformer
+    g = load_golden(fname)
+    cfg = iv.SWIN_CONFIGS[str(g["cfg_name"])]
+    m = SwinTransformer(img_size=cfg.img_size, patch_size=cfg.patch_size, num_classes=cfg.num_classes,
+                        embed_dim=cfg.embed_dim, depths=cfg.depths, num_heads=cfg.num_heads,
+                        window_size=cfg.window_size, mlp_ratio=cfg.mlp_ratio)
+    m.load_float_weights(iv.make_swin_weights(cfg, int(g["seed"]))).load_act_scales(golden_scales(g))
+    iv.freeze_model(m)
+    imgs = iv.make_images_int8(cfg, int(g["batch"]), int(g["images_seed"]))
+    cap = {}
+    if fname.startswith("micro"):
+        for name, mod in m.named_modules():
+            if f"site/{name}" in g.files:
+                mod.register_forward_hook(lambda mod, i, o, name=name: cap.__setitem__(name, o[0]))
+    with torch.no_grad():
+        acc, scale = m(dev(imgs))
+    for name, t in cap.items():
+        ref = g["site/" + name]
+        got = t.cpu().numpy()
+        if name == "patch_embed.proj":
+            got = got.reshape(got.shape[0], got.shape[1], -1).transpose(0, 2, 1)
+        assert np.array_equal(got.reshape(ref.shape).astype(np.float64), ref.astype(np.float64)), name
+    assert np.array_equal(acc.cpu().numpy(), g["logits_int"])
+    assert np.array_equal(scale.numpy(), g["logits_scale"])

@@ -112,3 +112,27 @@ def test_deit_logits_and_site_checksums(fname):
     # >= 2^22 is itself inexact (DESIGN.md "numerics contract"); every other site and the
     # integers derived downstream of matmul_2 must match exactly.
     assert all(b.endswith("attn.matmul_2") for b in bad), bad
+
+
+@pytest.mark.parametrize("fname,full", [("micro_swin_b2.npz", True), ("swin_tiny_b1.npz", False)])
+def test_swin_oracle_vs_reference(fname, full):
+    """OracleSwin (incl. masked 8-bit Shiftmax, rel-pos bias requant, token-order LayerNorm in
+    stage 0, patch merging, avg-pool) against every site the reference produced."""
+    g = load_golden(fname)
+    cfg = iv.SWIN_CONFIGS[str(g["cfg_name"])]
+    w = iv.make_swin_weights(cfg, int(g["seed"]))
+    assert _digest(w) == str(g["weights_sha256"])
+    o = orc.OracleSwin(cfg, w, golden_scales(g))
+    cap = {}
+    logits, s_head = o.forward(iv.make_images_int8(cfg, int(g["batch"]), int(g["images_seed"])), cap)
+    assert np.array_equal(logits, g["logits_int"])
+    assert np.array_equal(s_head, g["logits_scale"])
+    for n in g["sites"]:
+        n = str(n)
+        v = cap[n]
+        if "norm" in n.split(".")[-1]:
+            v = np.asarray(v, np.float64)
+        assert csum(v) == g["csum/" + n], n
+        if full:
+            ref = g["site/" + n]
+            assert np.array_equal(np.asarray(cap[n]).reshape(ref.shape).astype(np.float64), ref.astype(np.float64)), n

@@ -94,6 +94,48 @@ def model_fixture(models, cfg_name, batch, calib_batch, seed, full_sites, fname)
     print(fname, "sites", len(names), "bytes", os.path.getsize(os.path.join(OUT, fname)))
 
 
+def swin_fixture(models, cfg_name, batch, calib_batch, seed, full_sites, fname):
+    cfg = iv.SWIN_CONFIGS[cfg_name]
+    w = iv.make_swin_weights(cfg, seed)
+    m = rh.build_ref_swin(models, cfg, w)
+    rh.calibrate_and_freeze(models, m, iv.make_calibration_batch(cfg, calib_batch))
+    with torch.no_grad():
+        m(torch.zeros(1, 3, cfg.img_size, cfg.img_size))
+    sc = rh.act_scales(models, m)
+    q = iv.make_images_int8(cfg, batch)
+    y, recs = rh.capture(models, m, q.astype(np.float32) * sc["qact_input"])
+    d = {"cfg_name": cfg_name, "seed": seed, "batch": batch, "images_seed": 1, "weights_sha256": weights_digest(w)}
+    for k, v in sc.items():
+        d["scale/" + k] = np.float32(v)
+    names = []
+    for r in recs:
+        n = r["name"]
+        if n == "qact_input":
+            continue
+        v = site_value(r)
+        if n == "patch_embed.proj":
+            v = v.reshape(v.shape[0], v.shape[1], -1).transpose(0, 2, 1)
+        names.append(n)
+        if r["type"] == "IntLayerNorm":
+            v = np.asarray(v, np.float64)
+        d["csum/" + n] = csum(v)
+        if full_sites:
+            v = np.asarray(v)
+            if r["type"] == "IntLayerNorm":
+                d["site/" + n] = v.astype(np.float32)
+            else:
+                mx = np.abs(v).max() if v.size else 0
+                dt = np.int8 if mx < 128 else (np.int16 if mx < 32768 else np.int32)
+                if r["type"] == "IntSoftmax":
+                    dt = np.uint16
+                d["site/" + n] = v.astype(dt)
+    d["sites"] = np.array(names)
+    d["logits_int"] = recs[-1]["acc"].astype(np.int32)
+    d["logits_scale"] = recs[-1]["s_out"]
+    np.savez_compressed(os.path.join(OUT, fname), **d)
+    print(fname, "sites", len(names), "bytes", os.path.getsize(os.path.join(OUT, fname)))
+
+
 def frozen_act(models, bits, scale):
     a = models.QuantAct(bits)
     a.fix()
@@ -248,6 +290,8 @@ def main():
     model_fixture(models, "deit_small", 4, 4, 0, False, "deit_small_b4.npz")
     model_fixture(models, "deit_base", 2, 2, 0, False, "deit_base_b2.npz")
     model_fixture(models, "vit_base_384", 1, 1, 0, False, "vit_base_384_b1.npz")
+    swin_fixture(models, "micro_swin", 2, 4, 0, True, "micro_swin_b2.npz")
+    swin_fixture(models, "swin_tiny", 1, 1, 0, False, "swin_tiny_b1.npz")
 
 
 if __name__ == "__main__":

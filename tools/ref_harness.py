@@ -51,6 +51,21 @@ def build_ref_vit(models, cfg, weights):
     return m
 
 
+def build_ref_swin(models, cfg, weights):
+    from functools import partial
+    m = models.swin_quant.SwinTransformer(
+        img_size=cfg.img_size, patch_size=cfg.patch_size, in_chans=cfg.in_chans, num_classes=cfg.num_classes,
+        embed_dim=cfg.embed_dim, depths=list(cfg.depths), num_heads=list(cfg.num_heads),
+        window_size=cfg.window_size, mlp_ratio=cfg.mlp_ratio, norm_layer=partial(models.IntLayerNorm, eps=1e-6))
+    sd = {k: torch.from_numpy(v.copy()) for k, v in weights.items()}
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    for k in missing:
+        assert ("integer" in k) or ("scaling_factor" in k) or ("relative_position_index" in k) or ("attn_mask" in k), k
+    m.eval()
+    return m
+
+
 def calibrate_and_freeze(models, m, calib_fp32):
     with torch.no_grad():
         m(torch.from_numpy(calib_fp32))
@@ -99,11 +114,13 @@ def capture(models, m, x_fp32):
                     s_pre = inp[1]
                     r["s_pre"] = _np(s_pre.reshape(-1)).astype(np.float32)
                     # exactly the z_int the reference computes (quant_utils.py:220)
-                    sp = s_pre.reshape(1, -1) if x.dim() == 2 else s_pre.reshape(1, 1, -1)
+                    sp = s_pre.reshape(-1) if s_pre.numel() > 1 else s_pre.reshape(())
+                    if x.dim() == 4 and s_pre.numel() > 1:
+                        sp = s_pre.reshape(1, -1, 1, 1)
                     r["z"] = _np(torch.round(x / sp)).astype(np.float32)
                     if len(inp) > 2 and inp[2] is not None:
                         idt, s_id = inp[2], inp[3]
-                        si = s_id.reshape(1, -1) if idt.dim() == 2 else s_id.reshape(1, 1, -1)
+                        si = s_id.reshape(())
                         r["s_id"] = _np(s_id.reshape(-1)).astype(np.float32)
                         r["z_id"] = _np(torch.round(idt / si)).astype(np.float32)
                 else:
@@ -116,7 +133,8 @@ def capture(models, m, x_fp32):
                 r["acc"] = _np(torch.round(y / s_out.reshape(1, -1) if y.dim() == 2
                                            else y / s_out.reshape(1, 1, -1))).astype(np.int64)
                 r["w_int"] = _np(mod.weight_integer).astype(np.int32)
-                r["b_int"] = _np(mod.bias_integer).astype(np.int64)
+                if mod.bias_integer is not None:
+                    r["b_int"] = _np(mod.bias_integer).astype(np.int64)
                 r["s_w"] = _np(mod.fc_scaling_factor).astype(np.float32)
                 r["y_fp32"] = _np(y).astype(np.float32)
             elif isinstance(mod, models.QuantConv2d):
@@ -156,7 +174,7 @@ def capture(models, m, x_fp32):
                 x, s_in = inp
                 r["s_in"] = np.float32(s_in.reshape(-1)[0].item())
                 r["x"] = _np(torch.round(x / s_in)).astype(np.int32)
-                r["x_fp32_over_s"] = None
+                r["x_raw"] = _np(x).astype(np.float32)
                 r["s_out"] = np.float32(s_out.reshape(-1)[0].item())
                 r["bits"] = mod.output_bit
                 r["out"] = _np(torch.round(y / s_out)).astype(np.int32)
