@@ -98,6 +98,9 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="images per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=2)
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("IVIT_STREAMS", "4")),
+                    help="independent batch slices on separate HIP streams (VALU/MFMA overlap)")
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("IVIT_GRAPH", "1")), help="replay a captured hipGraph")
     args = ap.parse_args()
 
     import torch
@@ -113,11 +116,13 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # "nccl" is RCCL on ROCm; IVIT_DIST_BACKEND=gloo only for single-GPU plumbing tests
+        dist.init_process_group(os.environ.get("IVIT_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
 
     cfg = iv.CONFIGS[args.model]
     gname = {"deit_small": "deit_small_b4.npz", "deit_tiny": "deit_tiny_b1.npz"}[args.model]
@@ -137,12 +142,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.graph:
+        step = eng.capture(imgs, args.streams)
+    elif args.streams > 1:
+        step = lambda: eng.forward_streams(imgs, args.streams)
+    else:
+        step = lambda: eng.forward(imgs)
     for _ in range(args.warmup):
-        eng.forward(imgs)
+        step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        eng.forward(imgs)
+        step()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -155,7 +166,7 @@ def main():
     # parity guard inside the bench: first 4 images of rank 0 are the golden batch
     ok = None
     if rank == 0 and args.model == "deit_small" and args.batch >= 4:
-        logits = eng.forward(imgs)[:4].cpu().numpy()
+        logits = step()[:4].cpu().numpy()
         ok = bool(np.array_equal(logits, g["logits_int"]))
 
     # per-kernel HIP-event timing (separate instrumented steps, same stream)
@@ -191,7 +202,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "int8", "data": "synthetic",
             "config": {"workload": f"{cfg.name} int8 forward, batch {args.batch}/GPU, {cfg.img_size}x{cfg.img_size}x3 synthetic int8 "
                                    f"(BASELINE.json configs[1]); weights seeded synthetic, activation scales from the reference calibration",
-                       "global_batch": args.batch * world, "parallelism": f"dp{world} (batch-sharded, weights RCCL-broadcast once)"},
+                       "global_batch": args.batch * world, "parallelism": f"dp{world} (batch-sharded, weights RCCL-broadcast once)",
+                       "streams_per_gpu": args.streams, "hipgraph": bool(args.graph)},
             "model_int8_tops": round((lin_ops + bmm_ops) * args.batch * world / (ms_per_step * 1e-3) / 1e12, 1),
             "model_roofline_frac": round((lin_ops + bmm_ops) * args.batch / (ms_per_step * 1e-3) / 1e12 / INT8_PEAK_TOPS, 4),
             "bit_exact_vs_reference_golden": ok,

@@ -45,7 +45,7 @@ struct AttCfg {
     static constexpr int SMEM = SK_BYTES + SV_BYTES + SO_BYTES + 256 + 1024;
 };
 
-template <int NB>
+template <int NB, bool FAST>   // FAST: |c_qk|, |c_pv| < 2^9 (host-checked) -> rq_fast is exact
 __global__ __launch_bounds__(ATT_WAVES * 64) void attn_fused_kernel(AttnArgs p) {
     using C = AttCfg<NB>;
     extern __shared__ __attribute__((aligned(16))) char dsmem[];
@@ -106,6 +106,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void attn_fused_kernel(AttnArgs p) 
     const float nx0 = 15.0f * x0;
     const RcpC sr = rcp_prepare(s), x0r = rcp_prepare(x0);
     const double c_qk = p.dy_qk.m * p.dy_qk.r, c_pv = p.dy_pv.m * p.dy_pv.r;
+    // |q.k| <= 64*2^14 = 2^20 and |sum P*v| <= 2^15*2^7 = 2^22 (sum P <= 2^15): rq_fast is exact if |c| < 2^9
     const int ntile = (T + 15) >> 4;       // live 16-key tiles
     const int nqt = (T + 15) >> 4;         // query tiles
     const int nvec = T >> 3, size = nvec >> 2;
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void attn_fused_kernel(AttnArgs p) 
                 acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(kf, qf, acc, 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    int v = rq_c((double)acc[r], c_qk, -128, 127);
+                    int v = FAST ? min(max(rq_fast(acc[r], c_qk), -128), 127) : rq_c((double)acc[r], c_qk, -128, 127);
                     f[j][r] = sXq[v + 128];
                     if (j * 16 + 15 < T || j * 16 + g * 4 + r < T) qmax = max(qmax, v);
                 }
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void attn_fused_kernel(AttnArgs p) 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 int v = (int)((unsigned)oL[dt][r] + ((unsigned)oH[dt][r] << 8) + ((unsigned)cs << 14));
-                int o = rq_c((double)v, c_pv, -128, 127);
+                int o = FAST ? min(max(rq_fast(v, c_pv), -128), 127) : rq_c((double)v, c_pv, -128, 127);
                 so[(g * 4 + r) * 64 + dt * 16 + qi] = (char)o;
             }
         }

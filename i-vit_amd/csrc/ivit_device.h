@@ -46,6 +46,17 @@ __device__ __forceinline__ int rq_c(double z, double c, int lo, int hi) {
     return min(max(v, lo), hi);
 }
 
+// Fast exact form: t = fma(double(z), c, 1.5*2^52) rounds z*c to the nearest integer
+// (ties-to-even) inside the FMA and leaves it, two's complement, in the low dword of t.
+// Identical to rq_c whenever (1) z*m is exact in fp64, i.e. |z| < 2^22 (m <= 2^31), so the
+// reference's first rounding fl64(z*m) is a no-op, and (2) |z*c| < 2^31 (|c| < 2^9 given (1)),
+// so the low dword does not wrap where v_cvt_i32_f64 would saturate.  Callers check both.
+#define RQ_FAST_ZLIM (1 << 22)
+#define RQ_FAST_CLIM 512.0
+__device__ __forceinline__ int rq_fast(int z, double c) {
+    return __double2loint(__builtin_fma((double)z, c, 6755399441055744.0));
+}
+
 // ---- correctly-rounded fp32 division by a loop-invariant divisor --------------
 // Measured on MI355X (tools/ubench/valu_rates.hip): `a / b` (v_div_scale, v_rcp, 5 fma,
 // v_div_fmas, v_div_fixup) costs ~16x a v_mul_f32.  Every divisor on this path is a

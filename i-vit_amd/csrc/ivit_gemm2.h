@@ -19,13 +19,20 @@
 // v_rndne_f64, v_cvt_* all cost ~1.7x a v_mul_f32, so an fp32 "fast path" buys nothing.)
 // Packed dwords are staged in LDS and leave as whole 128/256-byte rows (16 B per lane).
 #pragma once
+#include <type_traits>
 #include "ivit_gemm.h"
 
-#define G2_BM 256
 #define G2_BN 128
 #define G2_BK 64
-#define G2_STAGE 24576          // 256*64 (A) + 128*64 (B)
-#define G2_SMEM (3 * G2_STAGE)  // 73728 >= 256*264 (int16 staging)
+// BM = 256 (8 waves, 2 blocks/CU) or 128 (4 waves, 3 blocks/CU: finer tiles for narrow-N GEMMs
+// whose 256-row tiling leaves the last block wave nearly empty, and more blocks in flight to
+// cover the cold-start latency of short-K tiles)
+template <int BM> struct G2Cfg {
+    static constexpr int THREADS = BM * 2;
+    static constexpr int STAGE = BM * 64 + 8192;       // A tile + B tile
+    static constexpr int SMEM = 3 * STAGE;             // >= BM*264 (int16 staging)
+    static constexpr int B_PER_THREAD = 512 / THREADS; // B chunks per thread
+};
 #define G2_LD8 136              // staged int8 row stride (bytes): 2-way-free ds_write_b32
 #define G2_LD16 264             // staged int16 row stride (bytes): conflict-free ds_write_b64
 
@@ -35,32 +42,38 @@ __device__ __forceinline__ int rq_lean(int z, double c, int lo, int hi) {
 }
 __device__ __forceinline__ int rq_lean_wide(int z, double c) { return (int)__builtin_rint((double)z * c); }
 
+template <int BM>
 __device__ __forceinline__ void g2_issue(const int8_t *A, const int8_t *B, int lda, int ldb, int M, int N,
                                          int row0, int col0, int k0, char *stage, int tid) {
+    using Cf = G2Cfg<BM>;
     const int wave = tid >> 6;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        int id = tid + i * 512, row = id >> 2, pos = id & 3;
+        int id = tid + i * Cf::THREADS, row = id >> 2, pos = id & 3;
         int c = pos ^ ((row >> 2) & 3);
         int grow = min(row0 + row, M - 1);
         const int8_t *src = A + (long long)grow * lda + k0 + c * 16;
-        unsigned loff = __builtin_amdgcn_readfirstlane((unsigned)(i * 8192 + wave * 1024));
+        unsigned loff = __builtin_amdgcn_readfirstlane((unsigned)(i * (Cf::THREADS * 16) + wave * 1024));
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                          (__attribute__((address_space(3))) void *)(stage + loff), 16, 0, 0);
     }
-    {
-        int id = tid, row = id >> 2, pos = id & 3;
+#pragma unroll
+    for (int i = 0; i < Cf::B_PER_THREAD; ++i) {
+        int id = tid + i * Cf::THREADS, row = id >> 2, pos = id & 3;
         int c = pos ^ ((row >> 2) & 3);
         int grow = min(col0 + row, N - 1);
         const int8_t *src = B + (long long)grow * ldb + k0 + c * 16;
-        unsigned loff = __builtin_amdgcn_readfirstlane((unsigned)(16384 + wave * 1024));
+        unsigned loff = __builtin_amdgcn_readfirstlane((unsigned)(BM * 64 + i * (Cf::THREADS * 16) + wave * 1024));
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                          (__attribute__((address_space(3))) void *)(stage + loff), 16, 0, 0);
     }
 }
 
-template <int EPI>
-__global__ __launch_bounds__(512, 4) void gemm_glds_kernel(GemmArgs p) {
+template <int EPI, int BM>
+__global__ __launch_bounds__(BM * 2, BM == 256 ? 4 : 3) void gemm_glds_kernel(GemmArgs p) {
+    using Cf = G2Cfg<BM>;
+    constexpr int G2_BM = BM, G2_STAGE = Cf::STAGE, G2_SMEM = Cf::SMEM, NT = Cf::THREADS;
+    constexpr int NLOADS = 2 + Cf::B_PER_THREAD;       // DMA loads per thread per K step
     __shared__ __attribute__((aligned(16))) char smem[G2_SMEM + 1536];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, half = lane >> 5;
@@ -77,8 +90,8 @@ __global__ __launch_bounds__(512, 4) void gemm_glds_kernel(GemmArgs p) {
     const int8_t *B = p.B;
 
     const int nk = p.K / G2_BK;
-    g2_issue(A, B, p.lda, p.ldb, p.M, p.N, row0, col0, 0, smem, tid);
-    if (nk > 1) g2_issue(A, B, p.lda, p.ldb, p.M, p.N, row0, col0, G2_BK, smem + G2_STAGE, tid);
+    g2_issue<BM>(A, B, p.lda, p.ldb, p.M, p.N, row0, col0, 0, smem, tid);
+    if (nk > 1) g2_issue<BM>(A, B, p.lda, p.ldb, p.M, p.N, row0, col0, G2_BK, smem + G2_STAGE, tid);
 
     // per-channel constants of this column block -> LDS (read back in the epilogue; the
     // K-loop barriers order the write): c[n] = m*2^-e (exact in fp64), bias[n]
@@ -87,7 +100,8 @@ __global__ __launch_bounds__(512, 4) void gemm_glds_kernel(GemmArgs p) {
     if (tid < G2_BN) {
         const int ch = col0 + tid;
         const bool in = ch < p.N;
-        sC[tid] = in ? p.dy_ch[ch].m * p.dy_ch[ch].r : 0.0;
+        const double cv = in ? p.dy_ch[ch].m * p.dy_ch[ch].r : 0.0;
+        sC[tid] = cv;
         sBias[tid] = (in && p.bias) ? p.bias[ch] : 0;
     }
 
@@ -101,20 +115,24 @@ __global__ __launch_bounds__(512, 4) void gemm_glds_kernel(GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
 
+    v4i a[2], b[2];
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (kt + 1 < nk) {
+            if (NLOADS == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (kt + 2 < nk)
-            g2_issue(A, B, p.lda, p.ldb, p.M, p.N, row0, col0, (kt + 2) * G2_BK,
+            g2_issue<BM>(A, B, p.lda, p.ldb, p.M, p.N, row0, col0, (kt + 2) * G2_BK,
                      smem + ((kt + 2) % 3) * G2_STAGE, tid);
         const char *sA = smem + (kt % 3) * G2_STAGE;
-        const char *sB = sA + 16384;
+        const char *sB = sA + BM * 64;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int chunk = kk * 2 + half;
-            v4i a[2], b[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 a[i] = *reinterpret_cast<const v4i *>(sA + lds_off(wm * 64 + i * 32 + (lane & 31), chunk));
@@ -142,42 +160,73 @@ __global__ __launch_bounds__(512, 4) void gemm_glds_kernel(GemmArgs p) {
     __syncthreads();   // every wave done with the ring before it is reused as the staging tile
 
     constexpr bool OUT8 = (EPI == EPI_RQ8_CH || EPI == EPI_QKV);
-    // ---- phase 1: requant + pack 4 channels per lane -> staged tile [token][channel]
+    constexpr int OLO = OUT8 ? -128 : -32768, OHI = OUT8 ? 127 : 32767;
+    // ---- phase 1: requant + pack 4 channels per lane -> staged tile [token][channel].
+    // Per 4-channel group the wave takes rq_fast when every |acc + bias| < 2^22 and |c| < 2^9
+    // (wave-uniform vote), else the 3-op reference form.
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int nl = wn * 64 + j * 32 + g * 8 + half * 4;
-            double c[4]; int bs[4];
+            double c[4];
+            int z[2][4];
+            bool ok = true;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { c[e] = sC[nl + e]; bs[e] = sBias[nl + e]; }
+            for (int e = 0; e < 4; ++e) {
+                c[e] = sC[nl + e];
+                const int bs = sBias[nl + e];
+                ok = ok && (fabs(c[e]) < RQ_FAST_CLIM);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int ml = wm * 64 + i * 32 + (lane & 31);
-                if (OUT8) {
-                    unsigned w = 0;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        w |= ((unsigned)rq_lean(acc[i][j][g * 4 + e] + bs[e], c[e], -128, 127) & 0xffu) << (8 * e);
-                    *reinterpret_cast<unsigned *>(smem + ml * G2_LD8 + nl) = w;
-                } else {
-                    int o[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = rq_lean(acc[i][j][g * 4 + e] + bs[e], c[e], -32768, 32767);
-                    v2i w = {(int)(((unsigned)o[0] & 0xffffu) | ((unsigned)o[1] << 16)),
-                             (int)(((unsigned)o[2] & 0xffffu) | ((unsigned)o[3] << 16))};
-                    *reinterpret_cast<v2i *>(smem + ml * G2_LD16 + nl * 2) = w;
+                for (int i = 0; i < 2; ++i) {
+                    z[i][e] = acc[i][j][g * 4 + e] + bs;
+                    ok = ok && ((unsigned)(z[i][e] + RQ_FAST_ZLIM) < (unsigned)(2 * RQ_FAST_ZLIM));
                 }
             }
+            if (p.dbg == 3) {   // ablation: no requant math, just stage the low bytes
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int ml = wm * 64 + i * 32 + (lane & 31);
+                    if (OUT8) *reinterpret_cast<unsigned *>(smem + ml * G2_LD8 + nl) = (unsigned)(z[i][0] ^ z[i][1] ^ z[i][2] ^ z[i][3]);
+                    else *reinterpret_cast<v2i *>(smem + ml * G2_LD16 + nl * 2) = v2i{z[i][0] ^ z[i][1], z[i][2] ^ z[i][3]};
+                }
+                continue;
+            }
+            const bool fast = __all(ok);
+            auto emit = [&](auto use_fast) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int ml = wm * 64 + i * 32 + (lane & 31);
+                    int o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int v = decltype(use_fast)::value ? rq_fast(z[i][e], c[e])
+                                                                : (int)__builtin_rint((double)z[i][e] * c[e]);
+                        o[e] = min(max(v, OLO), OHI);
+                    }
+                    if (OUT8) {
+                        unsigned w01 = __builtin_amdgcn_perm((unsigned)o[1], (unsigned)o[0], 0x0c0c0400u);
+                        unsigned w23 = __builtin_amdgcn_perm((unsigned)o[3], (unsigned)o[2], 0x0c0c0400u);
+                        *reinterpret_cast<unsigned *>(smem + ml * G2_LD8 + nl) = __builtin_amdgcn_perm(w23, w01, 0x05040100u);
+                    } else {
+                        v2i w = {(int)__builtin_amdgcn_perm((unsigned)o[1], (unsigned)o[0], 0x05040100u),
+                                 (int)__builtin_amdgcn_perm((unsigned)o[3], (unsigned)o[2], 0x05040100u)};
+                        *reinterpret_cast<v2i *>(smem + ml * G2_LD16 + nl * 2) = w;
+                    }
+                }
+            };
+            if (fast) emit(std::true_type{});
+            else emit(std::false_type{});
         }
     __syncthreads();
+    if (p.dbg == 2) return;   // ablation: no phase 2 (no global stores)
 
     // ---- phase 2: whole rows out, 16 bytes per lane
     if (EPI == EPI_RQ8_CH) {
         int8_t *out = reinterpret_cast<int8_t *>(p.out);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            int id = tid + i * 512, row = id >> 3, c = id & 7;
+            int id = tid + i * NT, row = id >> 3, c = id & 7;
             int grow = row0 + row, gcol = col0 + c * 16;
             if (grow < p.M && gcol < p.N) {
                 const char *sp = smem + row * G2_LD8 + c * 16;
@@ -194,9 +243,10 @@ __global__ __launch_bounds__(512, 4) void gemm_glds_kernel(GemmArgs p) {
     } else if (EPI == EPI_RQ16_CH || EPI == EPI_RQ16_CH_RES) {
         int16_t *out = reinterpret_cast<int16_t *>(p.out);
         const double cm = p.dy_main.m * p.dy_main.r, cr = p.dy_res.m * p.dy_res.r;
+        const bool res_fast = fabs(cm) < RQ_FAST_CLIM && fabs(cr) < RQ_FAST_CLIM;   // |int16 * c| < 2^24
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            int id = tid + i * 512, row = id >> 4, c = id & 15;
+            int id = tid + i * NT, row = id >> 4, c = id & 15;
             int grow = row0 + row, gcol = col0 + c * 8;
             if (grow < p.M && gcol < p.N) {
                 const char *sp = smem + row * G2_LD16 + c * 16;
@@ -218,8 +268,14 @@ __global__ __launch_bounds__(512, 4) void gemm_glds_kernel(GemmArgs p) {
                         int t0 = (int)(short)(v[w] & 0xffff), t1 = v[w] >> 16;
                         int r0 = (int)(short)(rs[w] & 0xffff), r1 = rs[w] >> 16;
                         // both terms are integers < 2^31: the sum is the reference's fp64 sum
-                        int o0 = rq_lean_wide(r0, cr) + rq_lean_wide(t0, cm);
-                        int o1 = rq_lean_wide(r1, cr) + rq_lean_wide(t1, cm);
+                        int o0, o1;
+                        if (__builtin_expect(res_fast, 1)) {
+                            o0 = rq_fast(r0, cr) + rq_fast(t0, cm);
+                            o1 = rq_fast(r1, cr) + rq_fast(t1, cm);
+                        } else {
+                            o0 = rq_lean_wide(r0, cr) + rq_lean_wide(t0, cm);
+                            o1 = rq_lean_wide(r1, cr) + rq_lean_wide(t1, cm);
+                        }
                         o0 = min(max(o0, -32768), 32767);
                         o1 = min(max(o1, -32768), 32767);
                         v[w] = (o0 & 0xffff) | (o1 << 16);
@@ -236,7 +292,7 @@ __global__ __launch_bounds__(512, 4) void gemm_glds_kernel(GemmArgs p) {
         // rows-fastest mapping: a wave covers 64 consecutive tokens of one 16-channel chunk
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            int id = tid + i * 512, row = id & 255, c = id >> 8;
+            int id = tid + i * NT, row = id & (BM - 1), c = id / BM;
             int grow = row0 + row, gcol = col0 + c * 16;
             if (grow < p.M && gcol < p.N) {
                 const char *sp = smem + row * G2_LD8 + c * 16;

@@ -103,10 +103,18 @@ static int launch_gemm(ivit_handle h, GemmArgs &a, int nb) {
 // production path for the QuantLinear GEMMs: K % 64 == 0, int8 A, requant epilogues
 template <int EPI>
 static int launch_gemm2(ivit_handle h, GemmArgs &a) {
-    const int tm = (a.M + G2_BM - 1) / G2_BM;
     a.tiles_n = (a.N + G2_BN - 1) / G2_BN;
     { static int dbg = -1; if (dbg < 0) { const char *e = getenv("IVIT_GEMM_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
-    gemm_glds_kernel<EPI><<<dim3((unsigned)(tm * a.tiles_n)), 512, 0, h->stream>>>(a);
+    static int force_bm = -1;
+    if (force_bm < 0) { const char *e = getenv("IVIT_GEMM_BM"); force_bm = e ? atoi(e) : 0; }
+    // tile height: estimated time ~ ceil(tiles / resident slots) * rows per tile; 256-row tiles run
+    // 2 per CU, 128-row tiles 3 per CU.  Ties go to the larger tile (better operand reuse).
+    const long long t256 = (long long)((a.M + 255) / 256) * a.tiles_n, t128 = (long long)((a.M + 127) / 128) * a.tiles_n;
+    const long long s256 = 2LL * h->num_cu, s128 = 3LL * h->num_cu;
+    const long long c256 = ((t256 + s256 - 1) / s256) * 256, c128 = ((t128 + s128 - 1) / s128) * 128;
+    const bool use128 = force_bm ? (force_bm == 128) : (c128 < c256);
+    if (use128) gemm_glds_kernel<EPI, 128><<<dim3((unsigned)t128), 256, 0, h->stream>>>(a);
+    else gemm_glds_kernel<EPI, 256><<<dim3((unsigned)t256), 512, 0, h->stream>>>(a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         snprintf(h->err, sizeof(h->err), "gemm2 launch: %s", hipGetErrorString(e));
@@ -231,18 +239,25 @@ int ivit_attn_pv_requant(ivit_handle h, const uint16_t *p, const int8_t *vt, ivi
 
 }  // extern "C"
 
-template <int NB>
-static int launch_attn(ivit_handle h, const AttnArgs &a, int BH) {
+template <int NB, bool FAST>
+static int launch_attn2(ivit_handle h, const AttnArgs &a, int BH) {
     const size_t lds = AttCfg<NB>::SMEM;
     if (lds > 65536) {
-        hipError_t e = hipFuncSetAttribute((const void *)attn_fused_kernel<NB>,
+        hipError_t e = hipFuncSetAttribute((const void *)attn_fused_kernel<NB, FAST>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { snprintf(h->err, sizeof(h->err), "attn attr: %s", hipGetErrorString(e)); return IVIT_ERR_HIP; }
     }
-    attn_fused_kernel<NB><<<BH, ATT_WAVES * 64, lds, h->stream>>>(a);
+    attn_fused_kernel<NB, FAST><<<BH, ATT_WAVES * 64, lds, h->stream>>>(a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(h->err, sizeof(h->err), "attn launch: %s", hipGetErrorString(e)); return IVIT_ERR_HIP; }
     return IVIT_OK;
+}
+
+template <int NB>
+static int launch_attn(ivit_handle h, const AttnArgs &a, int BH) {
+    const double cq = a.dy_qk.m * a.dy_qk.r, cp = a.dy_pv.m * a.dy_pv.r;
+    const bool fast = (cq < 512.0 && cq > -512.0 && cp < 512.0 && cp > -512.0);
+    return fast ? launch_attn2<NB, true>(h, a, BH) : launch_attn2<NB, false>(h, a, BH);
 }
 
 extern "C" int ivit_attention_fused(ivit_handle h, const int8_t *q, const int8_t *k, const int8_t *vt,

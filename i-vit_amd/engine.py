@@ -89,9 +89,10 @@ class ViTEngine:
         o, dt, shp = self.table["head.scale"]
         return self.blob[o:o + 4 * shp[0]].cpu().numpy().view(np.float32).copy()
 
-    def workspace(self, B):
-        if B in self._ws:
-            return self._ws[B]
+    def workspace(self, B, key=None):
+        wkey = (B, key)
+        if wkey in self._ws:
+            return self._ws[wkey]
         cfg, dev = self.cfg, self.device
         T, D, H, dh, Hd = cfg.num_tokens, cfg.embed_dim, cfg.num_heads, cfg.head_dim, cfg.hidden_dim
         ld = (T + 15) // 16 * 16
@@ -113,10 +114,44 @@ class ViTEngine:
             cls8=e(B, D, dt=torch.int8),
             logits=e(B, cfg.num_classes, dt=torch.int32),
         )
-        self._ws[B] = ws
+        self._ws[wkey] = ws
         return ws
 
-    def forward(self, images):
+    # ------------------------------------------------------------------ execution modes
+    def forward_streams(self, images, nstreams=2):
+        """Split the batch into `nstreams` independent slices, each on its own HIP stream, so that
+        the VALU-bound kernels of one slice (attention, LayerNorm, GELU table) can share the chip
+        with the MFMA-bound GEMMs of another.  Same integers as forward()."""
+        B = images.shape[0]
+        if not hasattr(self, "_streams") or len(self._streams) != nstreams:
+            self._streams = [torch.cuda.Stream(self.device) for _ in range(nstreams)]
+        cur = torch.cuda.current_stream(self.device)
+        bounds = [(B * i) // nstreams for i in range(nstreams + 1)]
+        outs = []
+        for i, st in enumerate(self._streams):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                outs.append(self.forward(images[bounds[i]:bounds[i + 1]], ws_key=("s", i)))
+        for st in self._streams:
+            cur.wait_stream(st)
+        return torch.cat(outs, 0)
+
+    def capture(self, images, nstreams=1):
+        """hipGraph capture of one forward (all kernels are capturable: no allocation / sync).
+        Returns a callable replaying the graph on the same `images` buffer -> logits tensor."""
+        run = (lambda: self.forward(images)) if nstreams <= 1 else (lambda: self.forward_streams(images, nstreams))
+        run()                                   # warm up: allocates workspaces outside the capture
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = run()
+
+        def replay():
+            g.replay()
+            return out
+        return replay
+
+    def forward(self, images, ws_key=None):
         """images: int8 device tensor [B, C, H, W] (already quantised, scale s_in).
         Returns int32 logits [B, num_classes] (head accumulators)."""
         cfg, call, f32, hc = self.cfg, self.h.call, self.f32, self.host
@@ -125,7 +160,7 @@ class ViTEngine:
         B = images.shape[0]
         T, D, H, dh, Hd = cfg.num_tokens, cfg.embed_dim, cfg.num_heads, cfg.head_dim, cfg.hidden_dim
         M = B * T
-        ws = self.workspace(B)
+        ws = self.workspace(B, ws_key)
         ld = ws["ld"]
         P = lambda t: _P(t.data_ptr())
         Kp = cfg.in_chans * cfg.patch_size ** 2

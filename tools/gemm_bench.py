@@ -16,7 +16,9 @@ def timeit(fn, n=20):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / n * 1e3
 rng = np.random.default_rng(0)
-for name, N, K in [("qkv", 1152, 384), ("proj", 384, 384), ("fc1", 1536, 384), ("fc2", 384, 1536)]:
+SHAPES = [("qkv", 1152, 384), ("proj", 384, 384), ("fc1", 1536, 384), ("fc2", 384, 1536)]
+if os.environ.get("GB_SHAPES"): SHAPES = [x for x in SHAPES if x[0] in os.environ["GB_SHAPES"].split(",")]
+for name, N, K in SHAPES:
     x = torch.from_numpy(rng.integers(-128, 128, (M, K), dtype=np.int8)).cuda()
     w = torch.from_numpy(rng.integers(-128, 128, (N, K), dtype=np.int8)).cuda()
     b = torch.from_numpy(rng.integers(-1000, 1000, N).astype(np.int32)).cuda()
