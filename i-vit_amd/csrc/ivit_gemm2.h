@@ -23,6 +23,9 @@
 #include "ivit_gemm.h"
 
 #define G2_BN 128
+#ifndef G2_NSTAGE128
+#define G2_NSTAGE128 2
+#endif
 #define G2_BK 64
 // BM = 256 (8 waves, 2 blocks/CU) or 128 (4 waves, 3 blocks/CU: finer tiles for narrow-N GEMMs
 // whose 256-row tiling leaves the last block wave nearly empty, and more blocks in flight to
@@ -30,7 +33,8 @@
 template <int BM> struct G2Cfg {
     static constexpr int THREADS = BM * 2;
     static constexpr int STAGE = BM * 64 + 8192;       // A tile + B tile
-    static constexpr int SMEM = 3 * STAGE;             // >= BM*264 (int16 staging)
+    static constexpr int NSTAGE = (BM == 256) ? 3 : G2_NSTAGE128;
+    static constexpr int SMEM = (NSTAGE * STAGE > BM * 264) ? NSTAGE * STAGE : BM * 264;   // ring, aliased by the staging tile
     static constexpr int B_PER_THREAD = 512 / THREADS; // B chunks per thread
 };
 #define G2_LD8 136              // staged int8 row stride (bytes): 2-way-free ds_write_b32
@@ -70,10 +74,11 @@ __device__ __forceinline__ void g2_issue(const int8_t *A, const int8_t *B, int l
 }
 
 template <int EPI, int BM>
-__global__ __launch_bounds__(BM * 2, BM == 256 ? 4 : 3) void gemm_glds_kernel(GemmArgs p) {
+__global__ __launch_bounds__(BM * 2, BM == 256 ? 4 : (G2_NSTAGE128 == 2 ? 4 : 3)) void gemm_glds_kernel(GemmArgs p) {
     using Cf = G2Cfg<BM>;
     constexpr int G2_BM = BM, G2_STAGE = Cf::STAGE, G2_SMEM = Cf::SMEM, NT = Cf::THREADS;
     constexpr int NLOADS = 2 + Cf::B_PER_THREAD;       // DMA loads per thread per K step
+    constexpr int NS = Cf::NSTAGE;                     // ring depth: loads run NS-1 steps ahead
     __shared__ __attribute__((aligned(16))) char smem[G2_SMEM + 1536];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, half = lane >> 5;
@@ -91,7 +96,7 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 4 : 3) void gemm_glds_kernel(Ge
 
     const int nk = p.K / G2_BK;
     g2_issue<BM>(A, B, p.lda, p.ldb, p.M, p.N, row0, col0, 0, smem, tid);
-    if (nk > 1) g2_issue<BM>(A, B, p.lda, p.ldb, p.M, p.N, row0, col0, G2_BK, smem + G2_STAGE, tid);
+    if (NS == 3 && nk > 1) g2_issue<BM>(A, B, p.lda, p.ldb, p.M, p.N, row0, col0, G2_BK, smem + G2_STAGE, tid);
 
     // per-channel constants of this column block -> LDS (read back in the epilogue; the
     // K-loop barriers order the write): c[n] = m*2^-e (exact in fp64), bias[n]
@@ -117,7 +122,7 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 4 : 3) void gemm_glds_kernel(Ge
 
     v4i a[2], b[2];
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) {
+        if (NS == 3 && kt + 1 < nk) {
             if (NLOADS == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         } else {
@@ -125,10 +130,10 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 4 : 3) void gemm_glds_kernel(Ge
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (kt + 2 < nk)
-            g2_issue<BM>(A, B, p.lda, p.ldb, p.M, p.N, row0, col0, (kt + 2) * G2_BK,
-                     smem + ((kt + 2) % 3) * G2_STAGE, tid);
-        const char *sA = smem + (kt % 3) * G2_STAGE;
+        if (kt + NS - 1 < nk)
+            g2_issue<BM>(A, B, p.lda, p.ldb, p.M, p.N, row0, col0, (kt + NS - 1) * G2_BK,
+                     smem + ((kt + NS - 1) % NS) * G2_STAGE, tid);
+        const char *sA = smem + (kt % NS) * G2_STAGE;
         const char *sB = sA + BM * 64;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {

@@ -110,7 +110,7 @@ static int launch_gemm2(ivit_handle h, GemmArgs &a) {
     // tile height: estimated time ~ ceil(tiles / resident slots) * rows per tile; 256-row tiles run
     // 2 per CU, 128-row tiles 3 per CU.  Ties go to the larger tile (better operand reuse).
     const long long t256 = (long long)((a.M + 255) / 256) * a.tiles_n, t128 = (long long)((a.M + 127) / 128) * a.tiles_n;
-    const long long s256 = 2LL * h->num_cu, s128 = 3LL * h->num_cu;
+    const long long s256 = 2LL * h->num_cu, s128 = (G2_NSTAGE128 == 2 ? 4LL : 3LL) * h->num_cu;
     const long long c256 = ((t256 + s256 - 1) / s256) * 256, c128 = ((t128 + s128 - 1) / s128) * 128;
     const bool use128 = force_bm ? (force_bm == 128) : (c128 < c256);
     if (use128) gemm_glds_kernel<EPI, 128><<<dim3((unsigned)t128), 256, 0, h->stream>>>(a);
