@@ -68,6 +68,15 @@ class EventTimer:
         return out
 
 
+def pmc_traffic():
+    """HBM bytes per GEMM launch from the committed rocprofv3 PMC passes of this command
+    (profiles/pmc_traffic.json: FETCH_SIZE x2-corrected + WRITE_SIZE); None if absent."""
+    try:
+        return round(json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["avg_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def cpu_baseline(cfg, weights, scales, target_seconds=15.0):
     """CPU oracle (port of the reference algorithm, OpenMP over the host cores) on a
     bounded sample of the same workload."""
@@ -188,7 +197,7 @@ def main():
             "bound": "mfma", "achieved": None if achieved is None else round(achieved, 1),
             "peak": INT8_PEAK_TOPS, "unit": "TOP/s",
             "frac": None if achieved is None else round(achieved / INT8_PEAK_TOPS, 4),
-            "traffic": None,
+            "traffic": pmc_traffic(),
             "launches_per_step": g_n, "ms_per_step_in_kernel": round(g_ms, 4),
             "avg_launch_ms": round(g_ms / g_n, 5) if g_n else None,
             "algorithmic_ops_per_step": lin_ops * args.batch,
