@@ -36,6 +36,48 @@ DEFK(k_f32rcp, float, 1.5f, B_F32RCP)
 DEFK(k_f32fma, float, 1.0f, B_F32FMA)
 DEFK(k_f32floor, float, 1.5f, B_F32FLOOR)
 DEFK(k_f32ldexp, float, 1.5f, B_F32LDEXP)
+typedef float v2f __attribute__((ext_vector_type(2)));
+__global__ void k_pkfma(float *out, int n) {   // v_pk_fma_f32: two fp32 FMAs per lane per instruction
+    v2f a[8];
+    for (int k = 0; k < 8; ++k) a[k] = v2f{1.0f + threadIdx.x + k, 0.5f + k};
+    for (int i = 0; i < n; ++i) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) asm volatile("v_pk_fma_f32 %0, %0, %0, %0" : "+v"(a[k]));
+    }
+    float s = 0;
+    for (int k = 0; k < 8; ++k) s += a[k][0] + a[k][1];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ void k_pkadd(float *out, int n) {
+    v2f a[8];
+    for (int k = 0; k < 8; ++k) a[k] = v2f{1.0f + threadIdx.x + k, 0.5f + k};
+    for (int i = 0; i < n; ++i) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) asm volatile("v_pk_add_f32 %0, %0, %0" : "+v"(a[k]));
+    }
+    float s = 0;
+    for (int k = 0; k < 8; ++k) s += a[k][0] + a[k][1];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ void k_ldsgather(float *out, int n) {   // dependent-free random ds_read_b32 over a 1 KB table
+    __shared__ float tbl[256];
+    tbl[threadIdx.x & 255] = threadIdx.x;
+    __syncthreads();
+    unsigned idx[8];
+    for (int k = 0; k < 8; ++k) idx[k] = (threadIdx.x * 2654435761u + k * 40503u) >> 8;
+    float s = 0;
+    for (int i = 0; i < n; ++i) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float v;
+            asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"((idx[k] & 255u) * 4u));
+            asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
+            idx[k] = idx[k] * 1664525u + 1013904223u + (unsigned)__float_as_int(v);
+        }
+    }
+    for (int k = 0; k < 8; ++k) s += idx[k];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
 __global__ void k_cvt64(double *out, int n) {   // cvt_f64_i32 + cvt_i32_f64 pair
     int a[8];
     for (int k = 0; k < 8; ++k) a[k] = threadIdx.x + k;
@@ -85,5 +127,8 @@ int main() {
     run("f64 add", k_f64add, (double *)buf, 8);
     run("f64 rndne", k_f64rnd, (double *)buf, 8);
     run("cvt64 pair", k_cvt64, (double *)buf, 16);
+    run("pk_fma_f32", k_pkfma, (float *)buf, 8);
+    run("pk_add_f32", k_pkadd, (float *)buf, 8);
+    run("lds gather(+2 valu)", k_ldsgather, (float *)buf, 8);
     return 0;
 }
