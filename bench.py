@@ -108,7 +108,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=2)
     ap.add_argument("--streams", type=int, default=int(os.environ.get("IVIT_STREAMS", "4")),
-                    help="independent batch slices on separate HIP streams (VALU/MFMA overlap)")
+                    help="batch slices on the runner's internal HIP streams (VALU/MFMA overlap)")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("IVIT_GRAPH", "1")), help="replay a captured hipGraph")
     args = ap.parse_args()
 
@@ -153,10 +153,8 @@ def main():
 
     if args.graph:
         step = eng.capture(imgs, args.streams)
-    elif args.streams > 1:
-        step = lambda: eng.forward_streams(imgs, args.streams)
     else:
-        step = lambda: eng.forward(imgs)
+        step = lambda: eng.forward(imgs, nslices=args.streams)
     for _ in range(args.warmup):
         step()
     barrier()
@@ -183,7 +181,7 @@ def main():
     if rank == 0 and args.profile_steps > 0:
         with EventTimer(eng.h, torch) as et:
             for _ in range(args.profile_steps):
-                eng.forward(imgs)
+                eng.forward_ops(imgs)      # same kernels, one C-ABI call per operator
             per = et.summary()
     if rank == 0:
         lin_ops, bmm_ops = model_ops_per_image(cfg)

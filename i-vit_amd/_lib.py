@@ -9,7 +9,7 @@ import subprocess
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 SO_PATH = os.environ.get("IVIT_LIB") or os.path.join(_CSRC, "libivit_hip.so")
-SOURCES = ["ivit_hip.hip", "ivit_device.h", "ivit_gemm.h", "ivit_elementwise.h", "ivit_attention.h", "ivit_gemm2.h", "ivit_swin.h"]
+SOURCES = ["ivit_hip.hip", "ivit_device.h", "ivit_gemm.h", "ivit_elementwise.h", "ivit_attention.h", "ivit_gemm2.h", "ivit_swin.h", "ivit_model.h"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
 
@@ -37,6 +37,39 @@ def build(force=False, verbose=False):
     return SO_PATH
 
 
+class VitConfig(ctypes.Structure):
+    """struct ivit_vit_config"""
+    _fields_ = [(n, ctypes.c_int) for n in ("img_size", "patch_size", "in_chans", "embed_dim", "depth", "num_heads",
+                                             "hidden_dim", "num_classes")]
+
+
+class VitBlock(ctypes.Structure):
+    """struct ivit_vit_block (device pointers + host scalars of one transformer block)"""
+    _fields_ = [
+        ("s_ln1", ctypes.c_float), ("n1_bias_int", ctypes.c_void_p), ("n1_sc", ctypes.c_void_p), ("n1_dy", ctypes.c_void_p),
+        ("qkv_w", ctypes.c_void_p), ("qkv_b", ctypes.c_void_p), ("qkv_dy", ctypes.c_void_p),
+        ("dy_qk", Dyadic), ("s_softmax", ctypes.c_float), ("dy_pv", Dyadic),
+        ("proj_w", ctypes.c_void_p), ("proj_b", ctypes.c_void_p), ("proj_dy", ctypes.c_void_p),
+        ("res1_main", Dyadic), ("res1_res", Dyadic),
+        ("s_ln2", ctypes.c_float), ("n2_bias_int", ctypes.c_void_p), ("n2_sc", ctypes.c_void_p), ("n2_dy", ctypes.c_void_p),
+        ("fc1_w", ctypes.c_void_p), ("fc1_b", ctypes.c_void_p), ("fc1_dy", ctypes.c_void_p),
+        ("s_gelu", ctypes.c_float), ("dy_gelu", Dyadic),
+        ("fc2_w", ctypes.c_void_p), ("fc2_b", ctypes.c_void_p), ("fc2_dy", ctypes.c_void_p),
+        ("res2_main", Dyadic), ("res2_res", Dyadic),
+    ]
+
+
+class VitParams(ctypes.Structure):
+    """struct ivit_vit_params"""
+    _fields_ = [
+        ("pe_w", ctypes.c_void_p), ("pe_b", ctypes.c_void_p), ("pe_dy", ctypes.c_void_p),
+        ("z_cls", ctypes.c_void_p), ("pos", ctypes.c_void_p), ("dy_x", Dyadic), ("dy_pos", Dyadic),
+        ("blocks_host", ctypes.POINTER(VitBlock)),
+        ("s_ln", ctypes.c_float), ("n_bias_int", ctypes.c_void_p), ("n_sc", ctypes.c_void_p), ("n_dy", ctypes.c_void_p),
+        ("head_w", ctypes.c_void_p), ("head_b", ctypes.c_void_p),
+    ]
+
+
 _P = ctypes.c_void_p
 _I = ctypes.c_int
 _L = ctypes.c_int64
@@ -48,6 +81,14 @@ SIGNATURES = {
     "ivit_destroy": [_P],
     "ivit_set_stream": [_P, _P],
     "ivit_quantize_input_f32": [_P, _P, _F, _P, _L],
+    "ivit_vit_create": [_P, ctypes.POINTER(VitConfig), ctypes.POINTER(VitParams), _I, ctypes.POINTER(_P)],
+    "ivit_vit_destroy": [_P],
+    "ivit_vit_workspace_bytes": [_P, _I, _I, ctypes.POINTER(ctypes.c_size_t)],
+    "ivit_vit_workspace_init": [_P, _P, ctypes.c_size_t, _I, _I],
+    "ivit_vit_forward": [_P, _P, _I, _I, _P, ctypes.c_size_t, _P],
+    "ivit_vit_graph_create": [_P, _P, _I, _I, _P, ctypes.c_size_t, _P, ctypes.POINTER(_P)],
+    "ivit_graph_launch": [_P],
+    "ivit_graph_destroy": [_P],
     "ivit_linear_i8": [_P, _P, _P, _P, _P, _I, _I, _I],
     "ivit_linear_i8_requant": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I],
     "ivit_linear_i8_requant_residual": [_P, _P, _P, _P, _P, Dyadic, Dyadic, _P, _P, _I, _I, _I],

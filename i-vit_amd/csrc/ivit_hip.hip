@@ -499,3 +499,5 @@ int ivit_embed_finish(ivit_handle h, const int16_t *patch16, const int32_t *z_cl
 }
 
 }  // extern "C"
+
+#include "ivit_model.h"

@@ -1,0 +1,273 @@
+// ivit_model.h — native runner for the frozen integer DeiT/ViT forward (include/ivit.h,
+// "whole-model runner").  Chains the C-ABI entry points of ivit_hip.hip in the order of the
+// reference's VisionTransformer.forward (vit_quant.py:254-282); owns the ShiftGELU tables, the
+// slice streams/events and the optional hipGraph.  Included at the end of ivit_hip.hip.
+#pragma once
+#include <vector>
+
+struct ivit_vit_s {
+    ivit_handle h;                    // the caller's handle (its stream is the parent stream)
+    ivit_vit_config cfg;
+    ivit_vit_params prm;
+    std::vector<ivit_vit_block> blocks;
+    int T, ld, Kp, num_patches;
+    bool fused_attention;
+    int8_t *gelu_tab;                 // [depth][65536]
+    int max_slices;
+    std::vector<ivit_handle> slice_h; // one handle per internal stream
+    std::vector<hipStream_t> streams;
+    std::vector<hipEvent_t> done;
+    hipEvent_t fork;
+};
+
+struct ivit_graph_s {
+    ivit_vit m;
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+};
+
+namespace {
+
+inline size_t al256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+// byte offsets of the per-slice buffers for `B` images
+struct SliceLayout {
+    size_t patches, patch16, xa, xb, a8, q, k, vt, ctx8, h8, g8, cls8, s8, p16, total;
+};
+
+SliceLayout slice_layout(const ivit_vit_s *m, int B) {
+    const ivit_vit_config &c = m->cfg;
+    const size_t M = (size_t)B * m->T, D = c.embed_dim, H = c.num_heads, dh = D / H, Hd = c.hidden_dim;
+    SliceLayout L;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o = al256(o + bytes); return at; };
+    L.patches = take((size_t)B * m->num_patches * m->Kp);
+    L.patch16 = take((size_t)B * m->num_patches * D * 2);
+    L.xa = take(M * D * 2);
+    L.xb = take(M * D * 2);
+    L.a8 = take(M * D);
+    L.q = take((size_t)B * H * m->T * dh);
+    L.k = take((size_t)B * H * m->T * dh);
+    L.vt = take((size_t)B * H * dh * m->ld);
+    L.ctx8 = take(M * D);
+    L.h8 = take(M * Hd);
+    L.g8 = take(M * Hd);
+    L.cls8 = take((size_t)B * D);
+    L.s8 = L.p16 = 0;
+    if (!m->fused_attention) {
+        L.s8 = take((size_t)B * H * m->T * m->ld);
+        L.p16 = take((size_t)B * H * m->T * m->ld * 2);
+    }
+    L.total = o;
+    return L;
+}
+
+inline int slice_begin(int batch, int nslices, int i) { return (int)(((long long)batch * i) / nslices); }
+inline int max_slice(int batch, int nslices) { return (batch + nslices - 1) / nslices; }
+
+// one slice on handle `h`
+int run_slice(const ivit_vit_s *m, ivit_handle h, const int8_t *images, int B, char *ws, int32_t *logits) {
+    const ivit_vit_config &c = m->cfg;
+    const ivit_vit_params &P = m->prm;
+    const int T = m->T, D = c.embed_dim, H = c.num_heads, dh = D / H, Hd = c.hidden_dim, ld = m->ld;
+    const int M = B * T;
+    const SliceLayout L = slice_layout(m, B);
+    int8_t *patches = (int8_t *)(ws + L.patches), *a8 = (int8_t *)(ws + L.a8), *q = (int8_t *)(ws + L.q),
+           *k = (int8_t *)(ws + L.k), *vt = (int8_t *)(ws + L.vt), *ctx8 = (int8_t *)(ws + L.ctx8),
+           *h8 = (int8_t *)(ws + L.h8), *g8 = (int8_t *)(ws + L.g8), *cls8 = (int8_t *)(ws + L.cls8);
+    int16_t *patch16 = (int16_t *)(ws + L.patch16), *x = (int16_t *)(ws + L.xa), *y = (int16_t *)(ws + L.xb);
+    int rc;
+#define RUN(call) do { rc = (call); if (rc != IVIT_OK) { if (h != m->h) snprintf(m->h->err, sizeof(m->h->err), "%s", h->err); return rc; } } while (0)
+    RUN(ivit_im2col_patch(h, images, B, c.in_chans, c.img_size, c.img_size, c.patch_size, patches));
+    RUN(ivit_linear_i8_requant(h, patches, P.pe_w, P.pe_b, P.pe_dy, 16, patch16, B * m->num_patches, D, m->Kp));
+    RUN(ivit_embed_finish(h, patch16, P.z_cls, P.pos, P.dy_x, P.dy_pos, x, B, T, D));
+    for (int i = 0; i < c.depth; ++i) {
+        const ivit_vit_block &b = m->blocks[i];
+        RUN(ivit_layernorm_requant(h, x, M, D, D, b.s_ln1, b.n1_bias_int, b.n1_sc, b.n1_dy, a8));
+        RUN(ivit_linear_i8_qkv(h, a8, b.qkv_w, b.qkv_b, b.qkv_dy, q, k, vt, B, T, H, dh, ld));
+        if (m->fused_attention) {
+            RUN(ivit_attention_fused(h, q, k, vt, b.dy_qk, b.s_softmax, b.dy_pv, ctx8, B, H, T, dh, ld));
+        } else {
+            int8_t *s8 = (int8_t *)(ws + L.s8);
+            uint16_t *p16 = (uint16_t *)(ws + L.p16);
+            RUN(ivit_attn_qk_requant(h, q, k, b.dy_qk, s8, B * H, T, dh, ld));
+            RUN(ivit_shiftmax(h, s8, (int64_t)B * H * T, T, ld, b.s_softmax, 16, p16, ld));
+            RUN(ivit_attn_pv_requant(h, p16, vt, b.dy_pv, ctx8, B, H, T, dh, ld, ld));
+        }
+        RUN(ivit_linear_i8_requant_residual(h, ctx8, b.proj_w, b.proj_b, b.proj_dy, b.res1_main, b.res1_res, x, y, M, D, D));
+        { int16_t *t = x; x = y; y = t; }
+        RUN(ivit_layernorm_requant(h, x, M, D, D, b.s_ln2, b.n2_bias_int, b.n2_sc, b.n2_dy, a8));
+        RUN(ivit_linear_i8_requant(h, a8, b.fc1_w, b.fc1_b, b.fc1_dy, 8, h8, M, Hd, D));
+        RUN(ivit_shiftgelu_requant_lut(h, h8, M, Hd, m->gelu_tab + (size_t)i * 65536, g8));
+        RUN(ivit_linear_i8_requant_residual(h, g8, b.fc2_w, b.fc2_b, b.fc2_dy, b.res2_main, b.res2_res, x, y, M, D, Hd));
+        { int16_t *t = x; x = y; y = t; }
+    }
+    // final norm on the class-token rows only (row stride T*D), then the head's int32 accumulators
+    RUN(ivit_layernorm_requant(h, x, B, D, (int64_t)T * D, P.s_ln, P.n_bias_int, P.n_sc, P.n_dy, cls8));
+    RUN(ivit_linear_i8(h, cls8, P.head_w, P.head_b, logits, B, c.num_classes, D));
+#undef RUN
+    return IVIT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ivit_vit_create(ivit_handle h, const ivit_vit_config *cfg, const ivit_vit_params *params, int max_slices,
+                    ivit_vit *out) {
+    CHECK_H(h);
+    REQUIRE(h, cfg && params && out && params->blocks_host, "null argument");
+    REQUIRE(h, cfg->depth > 0 && cfg->embed_dim > 0 && cfg->num_heads > 0 && cfg->embed_dim % cfg->num_heads == 0 &&
+                   cfg->patch_size > 0 && cfg->img_size % cfg->patch_size == 0 && cfg->hidden_dim > 0 &&
+                   cfg->num_classes > 0 && cfg->in_chans > 0,
+            "bad model configuration");
+    REQUIRE(h, max_slices >= 1 && max_slices <= 16, "max_slices must be in [1, 16]");
+    ivit_vit_s *m = new ivit_vit_s();
+    m->h = h;
+    m->cfg = *cfg;
+    m->prm = *params;
+    m->blocks.assign(params->blocks_host, params->blocks_host + cfg->depth);
+    m->prm.blocks_host = m->blocks.data();
+    const int g = cfg->img_size / cfg->patch_size;
+    m->num_patches = g * g;
+    m->T = m->num_patches + 1;
+    m->ld = (m->T + 15) / 16 * 16;
+    m->Kp = cfg->in_chans * cfg->patch_size * cfg->patch_size;
+    m->fused_attention = (cfg->embed_dim / cfg->num_heads == 64) && m->T <= 640;
+    m->gelu_tab = nullptr;
+    m->max_slices = max_slices;
+    m->fork = nullptr;
+    hipError_t e = hipMalloc((void **)&m->gelu_tab, (size_t)cfg->depth * 65536);
+    if (e != hipSuccess) {
+        snprintf(h->err, sizeof(h->err), "ivit_vit_create: hipMalloc: %s", hipGetErrorString(e));
+        delete m;
+        return IVIT_ERR_HIP;
+    }
+    for (int i = 0; i < cfg->depth; ++i) {
+        int rc = ivit_shiftgelu_build_table(h, m->blocks[i].s_gelu, m->blocks[i].dy_gelu, m->gelu_tab + (size_t)i * 65536);
+        if (rc != IVIT_OK) { hipFree(m->gelu_tab); delete m; return rc; }
+    }
+    if (max_slices > 1) {
+        hipEventCreateWithFlags(&m->fork, hipEventDisableTiming);
+        for (int i = 0; i < max_slices; ++i) {
+            hipStream_t st;
+            hipEvent_t ev;
+            if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+                snprintf(h->err, sizeof(h->err), "ivit_vit_create: stream/event creation failed");
+                ivit_vit_destroy(m);
+                return IVIT_ERR_HIP;
+            }
+            ivit_handle sh = nullptr;
+            ivit_create(&sh, h->device, st);
+            m->streams.push_back(st);
+            m->done.push_back(ev);
+            m->slice_h.push_back(sh);
+        }
+    }
+    *out = m;
+    return IVIT_OK;
+}
+
+int ivit_vit_destroy(ivit_vit m) {
+    if (!m) return IVIT_ERR_INVALID;
+    for (auto sh : m->slice_h) ivit_destroy(sh);
+    for (auto ev : m->done) hipEventDestroy(ev);
+    for (auto st : m->streams) hipStreamDestroy(st);
+    if (m->fork) hipEventDestroy(m->fork);
+    if (m->gelu_tab) hipFree(m->gelu_tab);
+    delete m;
+    return IVIT_OK;
+}
+
+int ivit_vit_workspace_bytes(ivit_vit m, int batch, int nslices, size_t *bytes) {
+    if (!m) return IVIT_ERR_INVALID;
+    REQUIRE(m->h, bytes && batch > 0 && nslices >= 1 && nslices <= m->max_slices && nslices <= batch, "bad arguments");
+    *bytes = slice_layout(m, max_slice(batch, nslices)).total * (size_t)nslices;
+    return IVIT_OK;
+}
+
+int ivit_vit_workspace_init(ivit_vit m, void *workspace, size_t bytes, int batch, int nslices) {
+    if (!m) return IVIT_ERR_INVALID;
+    size_t need = 0;
+    int rc = ivit_vit_workspace_bytes(m, batch, nslices, &need);
+    if (rc != IVIT_OK) return rc;
+    REQUIRE(m->h, workspace && bytes >= need, "workspace too small");
+    REQUIRE(m->h, ((uintptr_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
+    const SliceLayout L = slice_layout(m, max_slice(batch, nslices));
+    for (int i = 0; i < nslices; ++i) {
+        char *ws = (char *)workspace + L.total * (size_t)i;
+        const size_t vt_bytes = (size_t)max_slice(batch, nslices) * m->cfg.num_heads * (m->cfg.embed_dim / m->cfg.num_heads) * m->ld;
+        if (hipMemsetAsync(ws + L.vt, 0, vt_bytes, m->h->stream) != hipSuccess) return IVIT_ERR_HIP;
+        if (!m->fused_attention) {
+            const size_t pb = (size_t)max_slice(batch, nslices) * m->cfg.num_heads * m->T * m->ld * 2;
+            if (hipMemsetAsync(ws + L.p16, 0, pb, m->h->stream) != hipSuccess) return IVIT_ERR_HIP;
+        }
+    }
+    return IVIT_OK;
+}
+
+int ivit_vit_forward(ivit_vit m, const int8_t *images, int batch, int nslices, void *workspace, size_t bytes,
+                     int32_t *logits) {
+    if (!m) return IVIT_ERR_INVALID;
+    ivit_handle h = m->h;
+    size_t need = 0;
+    int rc = ivit_vit_workspace_bytes(m, batch, nslices, &need);
+    if (rc != IVIT_OK) return rc;
+    REQUIRE(h, images && logits && workspace && bytes >= need, "bad arguments / workspace too small");
+    REQUIRE(h, ((uintptr_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
+    const size_t img_bytes = (size_t)m->cfg.in_chans * m->cfg.img_size * m->cfg.img_size;
+    const size_t stride = slice_layout(m, max_slice(batch, nslices)).total;
+    if (nslices == 1) return run_slice(m, h, images, batch, (char *)workspace, logits);
+    if (hipEventRecord(m->fork, h->stream) != hipSuccess) return IVIT_ERR_HIP;
+    for (int i = 0; i < nslices; ++i) {
+        const int b0 = slice_begin(batch, nslices, i), b1 = slice_begin(batch, nslices, i + 1);
+        if (hipStreamWaitEvent(m->streams[i], m->fork, 0) != hipSuccess) return IVIT_ERR_HIP;
+        rc = run_slice(m, m->slice_h[i], images + (size_t)b0 * img_bytes, b1 - b0, (char *)workspace + stride * (size_t)i,
+                       logits + (size_t)b0 * m->cfg.num_classes);
+        if (rc != IVIT_OK) return rc;
+        if (hipEventRecord(m->done[i], m->streams[i]) != hipSuccess) return IVIT_ERR_HIP;
+    }
+    for (int i = 0; i < nslices; ++i)
+        if (hipStreamWaitEvent(h->stream, m->done[i], 0) != hipSuccess) return IVIT_ERR_HIP;
+    return IVIT_OK;
+}
+
+int ivit_vit_graph_create(ivit_vit m, const int8_t *images, int batch, int nslices, void *workspace, size_t bytes,
+                          int32_t *logits, ivit_graph *out) {
+    if (!m) return IVIT_ERR_INVALID;
+    ivit_handle h = m->h;
+    REQUIRE(h, out, "null argument");
+    REQUIRE(h, h->stream != nullptr, "graph capture needs a non-default stream on the handle");
+    hipError_t e = hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed);
+    if (e != hipSuccess) { snprintf(h->err, sizeof(h->err), "begin capture: %s", hipGetErrorString(e)); return IVIT_ERR_HIP; }
+    int rc = ivit_vit_forward(m, images, batch, nslices, workspace, bytes, logits);
+    hipGraph_t graph = nullptr;
+    e = hipStreamEndCapture(h->stream, &graph);
+    if (rc != IVIT_OK) { if (graph) hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess || !graph) { snprintf(h->err, sizeof(h->err), "end capture: %s", hipGetErrorString(e)); return IVIT_ERR_HIP; }
+    hipGraphExec_t exec = nullptr;
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) { hipGraphDestroy(graph); snprintf(h->err, sizeof(h->err), "instantiate: %s", hipGetErrorString(e)); return IVIT_ERR_HIP; }
+    ivit_graph_s *g = new ivit_graph_s();
+    g->m = m; g->graph = graph; g->exec = exec;
+    *out = g;
+    return IVIT_OK;
+}
+
+int ivit_graph_launch(ivit_graph g) {
+    if (!g) return IVIT_ERR_INVALID;
+    hipError_t e = hipGraphLaunch(g->exec, g->m->h->stream);
+    if (e != hipSuccess) { snprintf(g->m->h->err, sizeof(g->m->h->err), "graph launch: %s", hipGetErrorString(e)); return IVIT_ERR_HIP; }
+    return IVIT_OK;
+}
+
+int ivit_graph_destroy(ivit_graph g) {
+    if (!g) return IVIT_ERR_INVALID;
+    hipGraphExecDestroy(g->exec);
+    hipGraphDestroy(g->graph);
+    delete g;
+    return IVIT_OK;
+}
+
+}  // extern "C"

@@ -1,6 +1,10 @@
 """ViTEngine — frozen integer DeiT/ViT forward on one MI355X through the C-ABI.
 
-Mirrors the call order of the reference `VisionTransformer.forward`
+`forward` / `capture` hand the whole batch to the native runner (`ivit_vit_forward`,
+csrc/ivit_model.h): one C call per batch, slices on internal HIP streams, optional hipGraph.
+`forward_ops` issues the same kernels one C-ABI call at a time from Python (used by the
+per-operator timing in bench.py and by the parity tests of the unfused attention path).
+Both follow the call order of the reference `VisionTransformer.forward`
 (models/vit_quant.py:254-282; Block :130-143; Attention :59-88; Mlp
 layers_quant.py:144-153) with the QuantLinear->QuantAct, IntLayerNorm->QuantAct,
 IntGELU->QuantAct and QuantAct->QuantAct(identity) pairs fused into single kernels.
@@ -77,6 +81,102 @@ class ViTEngine:
             self.h.call("ivit_shiftgelu_build_table", self.f32[p + "mlp.s_gelu"], _dy(self.host[p + "mlp.dy_gelu"]),
                         _P(self.gelu_tab[i].data_ptr()))
 
+        self._build_native()
+
+    MAX_SLICES = 8
+
+    def _build_native(self):
+        """ivit_vit_create: hand the runner device pointers into the blob + host scalars."""
+        cfg, L = self.cfg, _lib
+        ptr = lambda name: self.blob.data_ptr() + self.table[name][0]
+        dy = lambda name: _dy(self.host[name])
+        blocks = (L.VitBlock * cfg.depth)()
+        for i in range(cfg.depth):
+            p, b = f"blocks.{i}.", blocks[i]
+            b.s_ln1, b.n1_bias_int, b.n1_sc, b.n1_dy = self.f32[p + "ln1.s"], ptr(p + "norm1.bias_int"), ptr(p + "norm1.sc"), ptr(p + "norm1.dy")
+            b.qkv_w, b.qkv_b, b.qkv_dy = ptr(p + "attn.qkv.w"), ptr(p + "attn.qkv.b"), ptr(p + "attn.qkv.dy")
+            b.dy_qk, b.s_softmax, b.dy_pv = dy(p + "attn.dy_qk"), self.f32[p + "attn.s_softmax"], dy(p + "attn.dy_pv")
+            b.proj_w, b.proj_b, b.proj_dy = ptr(p + "attn.proj.w"), ptr(p + "attn.proj.b"), ptr(p + "attn.proj.dy")
+            b.res1_main, b.res1_res = dy(p + "res1.dy_main"), dy(p + "res1.dy_res")
+            b.s_ln2, b.n2_bias_int, b.n2_sc, b.n2_dy = self.f32[p + "ln2.s"], ptr(p + "norm2.bias_int"), ptr(p + "norm2.sc"), ptr(p + "norm2.dy")
+            b.fc1_w, b.fc1_b, b.fc1_dy = ptr(p + "mlp.fc1.w"), ptr(p + "mlp.fc1.b"), ptr(p + "mlp.fc1.dy")
+            b.s_gelu, b.dy_gelu = self.f32[p + "mlp.s_gelu"], dy(p + "mlp.dy_gelu")
+            b.fc2_w, b.fc2_b, b.fc2_dy = ptr(p + "mlp.fc2.w"), ptr(p + "mlp.fc2.b"), ptr(p + "mlp.fc2.dy")
+            b.res2_main, b.res2_res = dy(p + "res2.dy_main"), dy(p + "res2.dy_res")
+        prm = L.VitParams()
+        prm.pe_w, prm.pe_b, prm.pe_dy = ptr("patch_embed.proj.w"), ptr("patch_embed.proj.b"), ptr("patch_embed.proj.dy")
+        prm.z_cls, prm.pos, prm.dy_x, prm.dy_pos = ptr("z_cls"), ptr("pos"), dy("embed.dy_x"), dy("embed.dy_pos")
+        prm.blocks_host = ctypes.cast(blocks, ctypes.POINTER(L.VitBlock))
+        prm.s_ln, prm.n_bias_int, prm.n_sc, prm.n_dy = self.f32["ln.s"], ptr("norm.bias_int"), ptr("norm.sc"), ptr("norm.dy")
+        prm.head_w, prm.head_b = ptr("head.w"), ptr("head.b")
+        c = L.VitConfig(cfg.img_size, cfg.patch_size, cfg.in_chans, cfg.embed_dim, cfg.depth, cfg.num_heads,
+                        cfg.hidden_dim, cfg.num_classes)
+        self.model = _P()
+        self.h._check(self.h.lib.ivit_vit_create(self.h.h, ctypes.byref(c), ctypes.byref(prm), self.MAX_SLICES,
+                                                 ctypes.byref(self.model)), "ivit_vit_create")
+        self._native_ws = {}
+
+    def __del__(self):
+        try:
+            if getattr(self, "model", None):
+                self.h.lib.ivit_vit_destroy(self.model)
+                self.model = None
+        except Exception:
+            pass
+
+    def _native_buffers(self, B, nslices):
+        key = (B, nslices)
+        if key not in self._native_ws:
+            n = ctypes.c_size_t()
+            self.h._check(self.h.lib.ivit_vit_workspace_bytes(self.model, B, nslices, ctypes.byref(n)), "ivit_vit_workspace_bytes")
+            ws = torch.empty(n.value, dtype=torch.uint8, device=self.device)
+            logits = torch.empty(B, self.cfg.num_classes, dtype=torch.int32, device=self.device)
+            self.h._check(self.h.lib.ivit_vit_workspace_init(self.model, _P(ws.data_ptr()), n.value, B, nslices), "ivit_vit_workspace_init")
+            self._native_ws[key] = (ws, logits)
+        return self._native_ws[key]
+
+    def forward(self, images, nslices=1):
+        """images: int8 device tensor [B, C, H, W] (already quantised, scale s_in) -> int32 logits
+        [B, num_classes] (head accumulators).  One native call; nslices > 1 cuts the batch into slices
+        on the runner's internal HIP streams (VALU-bound kernels of one slice share the chip with the
+        MFMA-bound GEMMs of another).  Same integers for every nslices."""
+        assert images.dtype == torch.int8 and images.is_contiguous() and images.device == self.device
+        self.h.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        B = images.shape[0]
+        nslices = max(1, min(int(nslices), B, self.MAX_SLICES))
+        ws, logits = self._native_buffers(B, nslices)
+        self.h._check(self.h.lib.ivit_vit_forward(self.model, _P(images.data_ptr()), B, nslices, _P(ws.data_ptr()),
+                                                  ws.numel(), _P(logits.data_ptr())), "ivit_vit_forward")
+        return logits
+
+    def forward_streams(self, images, nstreams=2):
+        return self.forward(images, nslices=nstreams)
+
+    def capture(self, images, nstreams=1):
+        """hipGraph of one forward on fixed buffers (ivit_vit_graph_create).  Returns a callable that
+        replays it and returns the logits tensor."""
+        B = images.shape[0]
+        nslices = max(1, min(int(nstreams), B, self.MAX_SLICES))
+        ws, logits = self._native_buffers(B, nslices)
+        if not hasattr(self, "_gstream"):
+            self._gstream = torch.cuda.Stream(self.device)
+        torch.cuda.synchronize(self.device)
+        self.h.set_stream(self._gstream.cuda_stream)
+        g = _P()
+        self.h._check(self.h.lib.ivit_vit_graph_create(self.model, _P(images.data_ptr()), B, nslices, _P(ws.data_ptr()),
+                                                       ws.numel(), _P(logits.data_ptr()), ctypes.byref(g)), "ivit_vit_graph_create")
+        self._graphs = getattr(self, "_graphs", []) + [g]
+        lib, gs, dev = self.h.lib, self._gstream, self.device
+
+        def replay():
+            cur = torch.cuda.current_stream(dev)
+            gs.wait_stream(cur)
+            self.h.set_stream(gs.cuda_stream)
+            self.h._check(lib.ivit_graph_launch(g), "ivit_graph_launch")
+            cur.wait_stream(gs)
+            return logits
+        return replay
+
     @classmethod
     def from_float(cls, cfg, weights, scales, device="cuda:0"):
         consts, f32 = freeze_vit(cfg, weights, scales)
@@ -117,43 +217,9 @@ class ViTEngine:
         self._ws[wkey] = ws
         return ws
 
-    # ------------------------------------------------------------------ execution modes
-    def forward_streams(self, images, nstreams=2):
-        """Split the batch into `nstreams` independent slices, each on its own HIP stream, so that
-        the VALU-bound kernels of one slice (attention, LayerNorm, GELU table) can share the chip
-        with the MFMA-bound GEMMs of another.  Same integers as forward()."""
-        B = images.shape[0]
-        if not hasattr(self, "_streams") or len(self._streams) != nstreams:
-            self._streams = [torch.cuda.Stream(self.device) for _ in range(nstreams)]
-        cur = torch.cuda.current_stream(self.device)
-        bounds = [(B * i) // nstreams for i in range(nstreams + 1)]
-        outs = []
-        for i, st in enumerate(self._streams):
-            st.wait_stream(cur)
-            with torch.cuda.stream(st):
-                outs.append(self.forward(images[bounds[i]:bounds[i + 1]], ws_key=("s", i)))
-        for st in self._streams:
-            cur.wait_stream(st)
-        return torch.cat(outs, 0)
-
-    def capture(self, images, nstreams=1):
-        """hipGraph capture of one forward (all kernels are capturable: no allocation / sync).
-        Returns a callable replaying the graph on the same `images` buffer -> logits tensor."""
-        run = (lambda: self.forward(images)) if nstreams <= 1 else (lambda: self.forward_streams(images, nstreams))
-        run()                                   # warm up: allocates workspaces outside the capture
-        torch.cuda.synchronize(self.device)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            out = run()
-
-        def replay():
-            g.replay()
-            return out
-        return replay
-
-    def forward(self, images, ws_key=None):
-        """images: int8 device tensor [B, C, H, W] (already quantised, scale s_in).
-        Returns int32 logits [B, num_classes] (head accumulators)."""
+    def forward_ops(self, images, ws_key=None):
+        """The same forward issued one C-ABI call per operator from Python (per-operator timing,
+        unfused-attention parity).  Returns int32 logits [B, num_classes]."""
         cfg, call, f32, hc = self.cfg, self.h.call, self.f32, self.host
         assert images.dtype == torch.int8 and images.is_contiguous() and images.device == self.device
         self.h.set_stream(torch.cuda.current_stream(self.device).cuda_stream)

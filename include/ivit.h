@@ -175,6 +175,68 @@ int ivit_embed_finish(ivit_handle h, const int16_t *patch16, const int32_t *z_cl
                       const int16_t *pos, ivit_dyadic dy_x, ivit_dyadic dy_pos, int16_t *x16,
                       int B, int T, int D);
 
+/* ---- a9-a11  whole-model runner: VisionTransformer.forward (vit_quant.py:254-282) with
+ * Block.forward (:130-143), Attention.forward (:59-88) and Mlp.forward (layers_quant.py:144-153)
+ * chained natively.  Replaces the Python module tree for inference on frozen constants: one C call
+ * per batch, nothing allocated after ivit_vit_create, the whole forward capturable in a hipGraph.
+ *
+ * All `const T *` members point into DEVICE memory owned by the caller (typically one packed blob
+ * that was broadcast once over RCCL); scalars and by-value dyadics are host values.            */
+typedef struct ivit_vit_config {
+    int img_size, patch_size, in_chans, embed_dim, depth, num_heads, hidden_dim, num_classes;
+} ivit_vit_config;
+
+typedef struct ivit_vit_block {
+    /* norm1 -> qact1 (vit_quant.py:131-132) */
+    float s_ln1; const float *n1_bias_int; const float *n1_sc; const ivit_dyadic *n1_dy;
+    /* attn.qkv -> qact1 (:63-65); q.k^T*scale -> qact_attn1 (:71-73); Shiftmax (:74);
+       attn.v -> qact2 (:77-79); proj -> qact3 (:80-82) */
+    const int8_t *qkv_w; const int32_t *qkv_b; const ivit_dyadic *qkv_dy;
+    ivit_dyadic dy_qk; float s_softmax; ivit_dyadic dy_pv;
+    const int8_t *proj_w; const int32_t *proj_b; const ivit_dyadic *proj_dy;
+    ivit_dyadic res1_main, res1_res;                       /* qact2 with identity (:134) */
+    /* norm2 -> qact3 (:135-136); mlp (layers_quant.py:144-153); qact4 with identity (:138) */
+    float s_ln2; const float *n2_bias_int; const float *n2_sc; const ivit_dyadic *n2_dy;
+    const int8_t *fc1_w; const int32_t *fc1_b; const ivit_dyadic *fc1_dy;
+    float s_gelu; ivit_dyadic dy_gelu;
+    const int8_t *fc2_w; const int32_t *fc2_b; const ivit_dyadic *fc2_dy;
+    ivit_dyadic res2_main, res2_res;
+} ivit_vit_block;
+
+typedef struct ivit_vit_params {
+    const int8_t *pe_w; const int32_t *pe_b; const ivit_dyadic *pe_dy;   /* patch_embed.proj -> qact */
+    const int32_t *z_cls; const int16_t *pos; ivit_dyadic dy_x, dy_pos;  /* cls token, pos_embed, qact1 */
+    const ivit_vit_block *blocks_host;                                   /* HOST array [depth]        */
+    float s_ln; const float *n_bias_int; const float *n_sc; const ivit_dyadic *n_dy;   /* norm -> qact2 */
+    const int8_t *head_w; const int32_t *head_b;                         /* head (int32 accumulators) */
+} ivit_vit_params;
+
+typedef struct ivit_vit_s *ivit_vit;
+
+/* Builds the per-layer ShiftGELU tables (device allocation happens here, never later) and
+ * `max_slices` internal streams/events for the sliced mode.                                     */
+int ivit_vit_create(ivit_handle h, const ivit_vit_config *cfg, const ivit_vit_params *params,
+                    int max_slices, ivit_vit *out);
+int ivit_vit_destroy(ivit_vit m);
+/* Caller-provided workspace: bytes for `batch` images cut into `nslices` slices.               */
+int ivit_vit_workspace_bytes(ivit_vit m, int batch, int nslices, size_t *bytes);
+/* Must run once per (workspace, batch, nslices) before the first forward (zeroes the padded
+ * key columns of the transposed V buffers); asynchronous on the handle's stream.               */
+int ivit_vit_workspace_init(ivit_vit m, void *workspace, size_t bytes, int batch, int nslices);
+/* images int8 [batch, in_chans, img, img] -> logits int32 [batch, num_classes].
+ * nslices == 1: everything on the handle's stream.  nslices > 1: the batch is cut into slices that
+ * run on internal streams forked from / joined to the handle's stream with events, so VALU-bound
+ * kernels of one slice overlap MFMA-bound GEMMs of another.  Same integers either way.          */
+int ivit_vit_forward(ivit_vit m, const int8_t *images, int batch, int nslices, void *workspace,
+                     size_t bytes, int32_t *logits);
+/* hipGraph of one ivit_vit_forward call with fixed buffers; launch replays it on the handle's
+ * stream.                                                                                      */
+typedef struct ivit_graph_s *ivit_graph;
+int ivit_vit_graph_create(ivit_vit m, const int8_t *images, int batch, int nslices, void *workspace,
+                          size_t bytes, int32_t *logits, ivit_graph *out);
+int ivit_graph_launch(ivit_graph g);
+int ivit_graph_destroy(ivit_graph g);
+
 /* ---- a12  Swin-specific operators (models/swin_quant.py)
  * IntSoftmax on `attn + mask` (:151-156): float mask [nW, n, n] (0 / -100.0) added to fl(Q*s)
  * before the division by s; row r of the flattened [B_, H, n] rows uses window (r/(H*n)) % nW.

@@ -307,9 +307,48 @@ def test_vit_forward_golden_logits(fname):
     g = load_golden(fname)
     cfg, w, eng = _engine_for(g)
     imgs = iv.make_images_int8(cfg, int(g["batch"]), int(g["images_seed"]))
-    logits = eng.forward(dev(imgs)).cpu().numpy()
+    d_imgs = dev(imgs)
+    logits = eng.forward(d_imgs).cpu().numpy()                 # native runner, one C call
     assert np.array_equal(logits, g["logits_int"])
     assert np.array_equal(eng.head_scale(), g["logits_scale"])
+    # one C-ABI call per operator from Python: same integers
+    assert np.array_equal(eng.forward_ops(d_imgs).cpu().numpy(), g["logits_int"])
+
+
+@pytest.mark.parametrize("fname,batch,nslices", [("deit_tiny_b1.npz", 5, 2), ("micro_vit2h_b3.npz", 7, 3),
+                                                   ("deit_small_b4.npz", 8, 4)])
+def test_native_runner_slices_and_graph(fname, batch, nslices):
+    """ivit_vit_forward with the batch cut into slices on internal streams, and the hipGraph of it,
+    give the integers of the single-stream forward (ragged slice sizes included)."""
+    g = load_golden(fname)
+    cfg, w, eng = _engine_for(g)
+    imgs = np.concatenate([iv.make_images_int8(cfg, int(g["batch"]), int(g["images_seed"])),
+                           iv.make_images_int8(cfg, batch, seed=7)])[:batch]
+    d_imgs = dev(imgs)
+    ref = eng.forward(d_imgs).cpu().numpy()
+    nb = min(batch, int(g["batch"]))
+    assert np.array_equal(ref[:nb], g["logits_int"][:nb])
+    assert np.array_equal(eng.forward(d_imgs, nslices=nslices).cpu().numpy(), ref)
+    replay = eng.capture(d_imgs, nslices)
+    for _ in range(3):
+        out = replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), ref)
+
+
+def test_native_runner_rejects_bad_workspace():
+    import ctypes
+    g = load_golden("micro_vit_b2.npz")
+    cfg, w, eng = _engine_for(g)
+    d_imgs = dev(iv.make_images_int8(cfg, 2, 1))
+    lib = eng.h.lib
+    n = ctypes.c_size_t()
+    assert lib.ivit_vit_workspace_bytes(eng.model, 2, 1, ctypes.byref(n)) == 0 and n.value > 0
+    assert lib.ivit_vit_workspace_bytes(eng.model, 2, 3, ctypes.byref(n)) != 0      # more slices than images
+    ws = torch.empty(1024, dtype=torch.uint8, device="cuda")
+    out = torch.empty(2, cfg.num_classes, dtype=torch.int32, device="cuda")
+    st = lib.ivit_vit_forward(eng.model, P(d_imgs), 2, 1, P(ws), 1024, P(out))
+    assert st != 0 and b"workspace" in lib.ivit_last_error(eng.h.h)
 
 
 def test_vit_forward_vs_oracle_residual_stream():
@@ -321,8 +360,9 @@ def test_vit_forward_vs_oracle_residual_stream():
     o = orc.OracleViT(cfg, w, golden_scales(g))
     cap = {}
     ref_logits, _ = o.forward(imgs, cap)
-    logits = eng.forward(dev(imgs)).cpu().numpy()
+    logits = eng.forward_ops(dev(imgs)).cpu().numpy()
     x_last = eng.last_x.cpu().numpy().reshape(3, cfg.num_tokens, cfg.embed_dim)
+    assert np.array_equal(eng.forward(dev(imgs)).cpu().numpy(), logits)
     assert np.array_equal(x_last, cap[f"blocks.{cfg.depth - 1}.qact4"].astype(np.int16))
     assert np.array_equal(logits, ref_logits)
 
