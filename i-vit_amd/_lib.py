@@ -81,6 +81,11 @@ SIGNATURES = {
     "ivit_destroy": [_P],
     "ivit_set_stream": [_P, _P],
     "ivit_quantize_input_f32": [_P, _P, _F, _P, _L],
+    "ivit_requant_i16": [_P, _P, _P, _I, _P, _P, _I, _P, _L, _I],
+    "ivit_layernorm_tokenorder_requant": [_P, _P, _L, _I, _F, _P, _P, _P, _I, _P],
+    "ivit_window_attention_fused": [_P, _P, Dyadic, Dyadic, _P, _F, Dyadic, _P, _I, _I, _I, _I, _I, _I],
+    "ivit_patch_merge_gather": [_P, _P, _I, _I, _I, _I, _P],
+    "ivit_widen_i8_i16": [_P, _P, _P, _L],
     "ivit_vit_create": [_P, ctypes.POINTER(VitConfig), ctypes.POINTER(VitParams), _I, ctypes.POINTER(_P)],
     "ivit_vit_destroy": [_P],
     "ivit_vit_workspace_bytes": [_P, _I, _I, ctypes.POINTER(ctypes.c_size_t)],

@@ -303,6 +303,16 @@ int ivit_requant_i32(ivit_handle h, const int32_t *z, const ivit_dyadic *dy, int
     return requant_any<int32_t>(h, z, dy, nch, z_id, dy_id, bits, out, rows, C);
 }
 
+int ivit_requant_i16(ivit_handle h, const int16_t *z, const ivit_dyadic *dy, int nch, const int32_t *z_id,
+                     const ivit_dyadic *dy_id, int bits, void *out, int64_t rows, int C) {
+    CHECK_H(h);
+    REQUIRE(h, z && dy && out && rows > 0 && C > 0, "bad arguments");
+    REQUIRE(h, nch == 1 || nch == C, "nch must be 1 or C");
+    REQUIRE(h, bits == 8 || bits == 16 || bits == 32, "bits must be 8, 16 or 32");
+    REQUIRE(h, (z_id == nullptr) == (dy_id == nullptr), "z_id and dy_id go together");
+    return requant_any<int16_t>(h, z, dy, nch, z_id, dy_id, bits, out, rows, C);
+}
+
 int ivit_requant_f32(ivit_handle h, const float *z, const ivit_dyadic *dy, int nch, const int32_t *z_id,
                      const ivit_dyadic *dy_id, int bits, void *out, int64_t rows, int C) {
     CHECK_H(h);
@@ -457,15 +467,30 @@ int ivit_avgpool_requant(ivit_handle h, const int8_t *x, int B, int L, int C, iv
     return IVIT_OK;
 }
 
+int ivit_layernorm_tokenorder_requant(ivit_handle h, const int16_t *x, int64_t rows, int C, float scale,
+                                      const float *bias_int, const float *sc, const ivit_dyadic *dy,
+                                      int tokens_per_image, int8_t *out8) {
+    CHECK_H(h);
+    REQUIRE(h, x && bias_int && sc && dy && out8 && rows > 0 && C > 0 && scale > 0.f && tokens_per_image > 0, "bad arguments");
+    const size_t lds = ((size_t)64 * (C + 1) + 3 * (size_t)C + 130) * sizeof(float) + (size_t)C * sizeof(double);
+    REQUIRE(h, lds <= 160 * 1024, "C too large for LDS staging");
+    int st = set_dyn_lds(h, (const void *)layernorm_tokenorder_kernel<true>, lds);
+    if (st) return st;
+    layernorm_tokenorder_kernel<true><<<(unsigned)((rows + 63) / 64), 256, lds, h->stream>>>(
+        x, rows, C, scale, bias_int, sc, dy, tokens_per_image, out8);
+    LAUNCH_CHECK(h);
+    return IVIT_OK;
+}
+
 int ivit_layernorm_tokenorder(ivit_handle h, const int16_t *x, int64_t rows, int C, float scale,
                               const float *bias_int, const float *sc, int tokens_per_image, float *z) {
     CHECK_H(h);
     REQUIRE(h, x && bias_int && sc && z && rows > 0 && C > 0 && scale > 0.f && tokens_per_image > 0, "bad arguments");
-    const size_t lds = (size_t)64 * (C + 1) * sizeof(float);
+    const size_t lds = ((size_t)64 * (C + 1) + 3 * (size_t)C + 130) * sizeof(float) + (size_t)C * sizeof(double);
     REQUIRE(h, lds <= 160 * 1024, "C too large for LDS staging");
     int st = set_dyn_lds(h, (const void *)layernorm_tokenorder_kernel<false>, lds);
     if (st) return st;
-    layernorm_tokenorder_kernel<false><<<(unsigned)((rows + 63) / 64), 64, lds, h->stream>>>(
+    layernorm_tokenorder_kernel<false><<<(unsigned)((rows + 63) / 64), 256, lds, h->stream>>>(
         x, rows, C, scale, bias_int, sc, nullptr, tokens_per_image, z);
     LAUNCH_CHECK(h);
     return IVIT_OK;
@@ -494,6 +519,51 @@ int ivit_embed_finish(ivit_handle h, const int16_t *patch16, const int32_t *z_cl
     CHECK_H(h);
     REQUIRE(h, patch16 && z_cls && pos && x16 && B > 0 && T > 1 && D > 0, "bad arguments");
     embed_finish_kernel<<<grid_for(h, (long long)B * T * D, 256), 256, 0, h->stream>>>(patch16, z_cls, pos, dy_x, dy_pos, x16, B, T, D);
+    LAUNCH_CHECK(h);
+    return IVIT_OK;
+}
+
+}  // extern "C"
+
+extern "C" {
+
+int ivit_window_attention_fused(ivit_handle h, const int8_t *qkv, ivit_dyadic dy_qk, ivit_dyadic dy_a,
+                                const int16_t *relb, float s_softmax, ivit_dyadic dy_pv, int8_t *ctx, int B, int R,
+                                int window, int shift, int heads, int dh) {
+    CHECK_H(h);
+    REQUIRE(h, qkv && relb && ctx && B > 0 && R > 0 && heads > 0, "bad arguments");
+    if (window != 7 || dh != 32 || (R % 7) != 0) {
+        snprintf(h->err, sizeof(h->err), "%s: built for window 7, head dim 32, R %% 7 == 0", __func__);
+        return IVIT_ERR_UNSUPPORTED;
+    }
+    REQUIRE(h, shift >= 0 && shift < 7 && s_softmax > 0.f, "bad shift / scale");
+    // magic-number rounding needs |z*c| < 2^31 with |q.k| <= 2^19 and |sum P*v| <= 2^20
+    REQUIRE(h, fabs(dy_qk.m * dy_qk.r) < 2048.0 && fabs(dy_pv.m * dy_pv.r) < 1024.0, "requant factor out of range");
+    WinAttnArgs a;
+    a.qkv = qkv; a.ctx = ctx; a.relb = relb; a.B = B; a.R = R; a.shift = shift; a.heads = heads;
+    a.dy_qk = dy_qk; a.dy_a = dy_a; a.dy_pv = dy_pv; a.s = s_softmax;
+    a.units = (long long)B * (R / 7) * (R / 7) * heads;
+    window_attention_kernel<<<dim3((unsigned)((a.units + 3) / 4)), 256, 0, h->stream>>>(a);
+    LAUNCH_CHECK(h);
+    return IVIT_OK;
+}
+
+int ivit_patch_merge_gather(ivit_handle h, const void *x, int in_bits, int B, int R, int C, int16_t *out) {
+    CHECK_H(h);
+    REQUIRE(h, x && out && B > 0 && R > 0 && (R % 2) == 0 && C > 0 && (C % 8) == 0, "bad arguments (C must be a multiple of 8)");
+    REQUIRE(h, in_bits == 8 || in_bits == 16, "in_bits must be 8 or 16");
+    const long long total = (long long)B * R * R * C / 8;
+    if (in_bits == 8) patch_merge_gather_kernel<int8_t><<<grid_for(h, total, 1024), 256, 0, h->stream>>>((const int8_t *)x, B, R, C, out);
+    else patch_merge_gather_kernel<int16_t><<<grid_for(h, total, 1024), 256, 0, h->stream>>>((const int16_t *)x, B, R, C, out);
+    LAUNCH_CHECK(h);
+    return IVIT_OK;
+}
+
+int ivit_widen_i8_i16(ivit_handle h, const int8_t *x, int16_t *out, int64_t n) {
+    CHECK_H(h);
+    REQUIRE(h, x && out && n >= 0, "bad arguments");
+    if (n == 0) return IVIT_OK;
+    widen_i8_i16_kernel<<<grid_for(h, n, 1024), 256, 0, h->stream>>>(x, out, n);
     LAUNCH_CHECK(h);
     return IVIT_OK;
 }

@@ -120,51 +120,305 @@ __device__ __forceinline__ float strided_order_sum(const float *x, int n, bool i
     return ps0;
 }
 
+// 64 tokens per 256-thread block: the loads (with fl(fl(Q*s)/s)) and the normalise / requant / store pass
+// are spread over all threads; only the two order-sensitive sums and the integer square root of a token run
+// on one thread (wave 0, one token per lane).  Per-channel divisors use the hoisted reciprocal (lean_div).
 template <bool OUT8>
-__global__ __launch_bounds__(64) void layernorm_tokenorder_kernel(const int16_t *__restrict__ x, long long rows, int C,
-                                                                  float s, const float *__restrict__ bias_int,
-                                                                  const float *__restrict__ sc,
-                                                                  const ivit_dyadic *__restrict__ dy, int L,
-                                                                  void *__restrict__ out) {
+__global__ __launch_bounds__(256) void layernorm_tokenorder_kernel(const int16_t *__restrict__ x, long long rows, int C,
+                                                                   float s, const float *__restrict__ bias_int,
+                                                                   const float *__restrict__ sc,
+                                                                   const ivit_dyadic *__restrict__ dy, int L,
+                                                                   void *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char dsmem[];
-    float *tile = reinterpret_cast<float *>(dsmem);   // [64][C + 1]
     const int LD = C + 1;
+    float *tile = reinterpret_cast<float *>(dsmem);            // [64][C + 1]
+    float *cSc = tile + 64 * LD, *cY = cSc + C, *cB = cY + C;  // per-channel sc, refined 1/sc, bias_int
+    float *rMean = cB + C, *rF = rMean + 64;                   // per-token mean and factor
+    double *cC = reinterpret_cast<double *>(rF + 64 + ((64 * LD + 3 * C + 128) & 1));   // 8-byte aligned
     const int tid = threadIdx.x;
     const long long row0 = (long long)blockIdx.x * 64;
     const RcpC sr = rcp_prepare(s);
-    // coalesced load of up to 64 rows
-    for (long long e = tid; e < (long long)64 * C; e += 64) {
-        const int r = (int)(e / C), c = (int)(e - (long long)r * C);
+    for (int c = tid; c < C; c += 256) {
+        const float scv = sc[c];
+        cSc[c] = scv;
+        cY[c] = rcp_prepare(scv).y;
+        cB[c] = bias_int[c];
+        if (OUT8) cC[c] = dy[c].m * dy[c].r;
+    }
+    const int total = 64 * C;
+    for (int e = tid; e < total; e += 256) {
+        const int r = e / C, c = e - r * C;
         const long long gr = row0 + r;
         tile[r * LD + c] = gr < rows ? requotient_c((float)x[gr * C + c], sr) : 0.f;
     }
     __syncthreads();
-    const long long row = row0 + tid;
-    float *xr = tile + tid * LD;
-    if (row < rows) {
-        const bool ilp4 = (row % L) >= (L / 32) * 32;
-        const float sum = strided_order_sum(xr, C, ilp4, false, 0.f);
-        const float mean = rintf(sum / (float)C);
-        const float var = strided_order_sum(xr, C, ilp4, true, mean);
-        float k = 65536.0f;
-        for (int n = 0; n < 10; ++n) k = floorf((k + floorf(var / k)) * 0.5f);
-        const float F = floorf((1.0f / k) * 2147483648.0f);
-        for (int c = 0; c < C; ++c) {
-            const float y = xr[c] - mean;
-            const float yi = floorf((y * F) * 0.5f);
-            const float o = yi + bias_int[c];
-            const float scv = sc[c];
-            xr[c] = rintf((o * scv) / scv);
+    if (tid < 64) {
+        const long long row = row0 + tid;
+        const float *xr = tile + tid * LD;
+        float mean = 0.f, F = 0.f;
+        if (row < rows) {
+            const bool ilp4 = (row % L) >= (L / 32) * 32;
+            const float sum = strided_order_sum(xr, C, ilp4, false, 0.f);
+            mean = rintf(sum / (float)C);
+            const float var = strided_order_sum(xr, C, ilp4, true, mean);
+            float k = 65536.0f;
+            for (int n = 0; n < 10; ++n) {          // the iteration is idempotent once it has converged
+                const float kn = floorf((k + floorf(var / k)) * 0.5f);
+                if (kn == k) break;
+                k = kn;
+            }
+            F = floorf((1.0f / k) * 2147483648.0f);
         }
+        rMean[tid] = mean;
+        rF[tid] = F;
     }
     __syncthreads();
-    for (long long e = tid; e < (long long)64 * C; e += 64) {
-        const int r = (int)(e / C), c = (int)(e - (long long)r * C);
+    for (int e = tid; e < total; e += 256) {
+        const int r = e / C, c = e - r * C;
         const long long gr = row0 + r;
-        if (gr < rows) {
-            const float zv = tile[r * LD + c];
-            if (OUT8) reinterpret_cast<int8_t *>(out)[gr * C + c] = (int8_t)rq_c((double)zv, dy[c].m * dy[c].r, -128, 127);
-            else reinterpret_cast<float *>(out)[gr * C + c] = zv;
+        if (gr >= rows) continue;
+        const float y = tile[r * LD + c] - rMean[r];
+        const float yi = floorf((y * rF[r]) * 0.5f);
+        const float o = yi + cB[c];
+        RcpC rc;
+        rc.d = cSc[c];
+        rc.y = cY[c];
+        const float zv = rintf(lean_div(o * rc.d, rc));
+        if (OUT8) reinterpret_cast<int8_t *>(out)[gr * C + c] = (int8_t)rq_c((double)zv, cC[c], -128, 127);
+        else reinterpret_cast<float *>(out)[gr * C + c] = zv;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// a12 fused windowed attention (WindowAttention.forward, swin_quant.py:121-169, between the qkv
+// QuantAct and proj), window 7x7 (N = 49 tokens), head dim 32.  One wavefront per (image, window,
+// head); cyclic shift, window partition and their inverses are index arithmetic on the natural
+// [B, R, R, 3C] qkv tensor and [B, R*R, C] context tensor — no permuted copies.
+//
+//   S^T = K Q^T      v_mfma_i32_32x32x32_i8, K = dh = 32: lane holds query (lane & 31) and 16 keys
+//                    per 32-key tile -> a query's row of 49 sits in 2 lanes x (16 + 9) registers
+//   a   = clamp8(rq(clamp8(rq(S, dy_qk)), dy_a) + relb[h][q][k])      (qact_attn1, qact2 + bias)
+//   P   = Shiftmax_8bit(a (+ shift mask))   torch's sum order for n = 49 is lane-local:
+//         p[l] = ((((x[l]+x[32+l])+x[40+l])+x[8+l])+x[16+l])+x[24+l],  S = x[48]+p[0]+...+p[7]
+//   O^T = V^T P^T    the P registers ARE the B fragments (same key permutation on both operands);
+//         P <= 128 does not fit int8: two MFMAs, B = P - 64 and B = 64
+//   out = clamp8(rq(O, dy_pv)) -> 16-byte stores at the token's natural position
+typedef int v16i_sw __attribute__((ext_vector_type(16)));
+struct WinAttnArgs {
+    const int8_t *qkv;      // [B, R, R, 3, heads, 32]
+    int8_t *ctx;            // [B, R*R, heads*32]
+    const int16_t *relb;    // [heads, 49, 49]: rq(quantised relative position bias, dy_table -> qact2)
+    int B, R, shift, heads;
+    ivit_dyadic dy_qk, dy_a, dy_pv;
+    float s;                // Shiftmax input scale (qact2)
+    long long units;        // B * (R/7)^2 * heads
+};
+
+__global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs p) {
+    __shared__ __attribute__((aligned(16))) char sm[4 * (2048 + 4816 + 64) + 512 + 1024];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    char *sV = sm + wave * 2048;                                            // [64 keys][32 d]
+    int16_t *sRel = reinterpret_cast<int16_t *>(sm + 4 * 2048 + wave * 4816);   // [49][49]
+    unsigned char *sReg = reinterpret_cast<unsigned char *>(sm + 4 * (2048 + 4816) + wave * 64);
+    int16_t *sTa = reinterpret_cast<int16_t *>(sm + 4 * (2048 + 4816 + 64));    // rq(v, dy_a), v = -128..127
+    float *sTx = reinterpret_cast<float *>(sm + 4 * (2048 + 4816 + 64) + 512);  // fl(fl(a*s)/s)
+    const float s = p.s;
+    const RcpC sr = rcp_prepare(s);
+    {
+        const double ca = p.dy_a.m * p.dy_a.r;
+        sTa[tid] = (int16_t)(int)__builtin_rint((double)(tid - 128) * ca);
+        sTx[tid] = requotient_c((float)(tid - 128), sr);
+    }
+    __syncthreads();
+    const long long unit = (long long)blockIdx.x * 4 + wave;
+    if (unit >= p.units) return;
+    const int R = p.R, nw = R / 7, C = p.heads * 32;
+    const int head = (int)(unit % p.heads);
+    const long long wlin = unit / p.heads;
+    const int win = (int)(wlin % (nw * nw)), b = (int)(wlin / (nw * nw));
+    const int wi = win / nw, wj = win - wi * nw;
+    auto tok_off = [&](int n) -> long long {                 // natural token index of window token n
+        const int wy = n / 7, wx = n - wy * 7;
+        int y = wi * 7 + wy + p.shift, x = wj * 7 + wx + p.shift;
+        y = y >= R ? y - R : y;
+        x = x >= R ? x - R : x;
+        return ((long long)b * R + y) * R + x;
+    };
+    const bool masked = p.shift > 0 && (wi == nw - 1 || wj == nw - 1);
+
+    // ---- operands: Q / K fragments straight from global, V rows and the bias slab through LDS
+    v4i qf[2], kf[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int n = t * 32 + l31;
+        qf[t] = v4i{0, 0, 0, 0};
+        kf[t] = v4i{0, 0, 0, 0};
+        if (n < 49) {
+            const int8_t *row = p.qkv + tok_off(n) * (3 * C) + head * 32 + half * 16;
+            qf[t] = *reinterpret_cast<const v4i *>(row);
+            kf[t] = *reinterpret_cast<const v4i *>(row + C);
         }
     }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int piece = lane + i * 64, n = piece >> 1, hh = piece & 1;    // 128 pieces of 16 B
+        v4i v = {0, 0, 0, 0};
+        if (n < 49) v = *reinterpret_cast<const v4i *>(p.qkv + tok_off(n) * (3 * C) + 2 * C + head * 32 + hh * 16);
+        *reinterpret_cast<v4i *>(sV + n * 32 + hh * 16) = v;
+    }
+    {
+        const int16_t *rb = p.relb + (long long)head * 2401;
+        for (int i = lane; i < 2401; i += 64) sRel[i] = rb[i];
+    }
+    if (lane < 49) {
+        const int wy = lane / 7, wx = lane - wy * 7, ys = wi * 7 + wy, xs = wj * 7 + wx;
+        const int ry = ys < R - 7 ? 0 : (ys < R - p.shift ? 1 : 2), rx = xs < R - 7 ? 0 : (xs < R - p.shift ? 1 : 2);
+        sReg[lane] = (unsigned char)(ry * 3 + rx);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // V^T fragments (A operand of O^T = V^T P^T): row d = lane & 31, byte i of key tile kt = key
+    // 32kt + (i&3) + 8(i>>2) + 4*half — the order in which this lane's S^T registers hold the keys
+    v4i vf[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            unsigned word = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int key = 32 * kt + e + 8 * w + 4 * half;
+                word |= (unsigned)(unsigned char)sV[key * 32 + l31] << (8 * e);
+            }
+            vf[kt][w] = (int)word;
+        }
+
+    const double c_qk = p.dy_qk.m * p.dy_qk.r, c_pv = p.dy_pv.m * p.dy_pv.r;
+    const float x0 = floorf(-1.0f / s), nx0 = 15.0f * x0;
+    const RcpC x0r = rcp_prepare(x0);
+    const v4i c64 = {0x40404040, 0x40404040, 0x40404040, 0x40404040};
+
+#pragma unroll 1
+    for (int qt = 0; qt < 2; ++qt) {
+        const int q = qt * 32 + l31;                       // this lane's query (rows >= 49 are padding)
+        const bool qlive = q < 49;
+        const int qq = qlive ? q : 48;
+        v16i_sw acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0; acc1[r] = 0; }
+        acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf[0], qf[qt], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf[1], qf[qt], acc1, 0, 0, 0);
+        // valid keys: tile 0 all 16 registers; tile 1 registers 0..7 (keys 32..47) and, for half 0, r = 8 (key 48)
+        float f[25];
+        const int regq = sReg[qq];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 25; ++i) {
+            const int kt = i < 16 ? 0 : 1, r = i < 16 ? i : i - 16;
+            const int key = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * half;      // < 49 except i == 24 on half 1
+            const int kk = (i == 24 && half) ? 48 : key;
+            const int z = kt ? acc1[r] : acc0[r];
+            const int v = min(max(__double2loint((double)z * c_qk + 6755399441055744.0), -128), 127);
+            const int a = min(max((int)sTa[v + 128] + (int)sRel[qq * 49 + kk], -128), 127);
+            float xt;
+            if (masked) {
+                float X = (float)a * s;
+                X = X + ((sReg[kk] != regq) ? -100.0f : 0.0f);
+                xt = lean_div(X, sr);
+            } else {
+                xt = sTx[a + 128];
+            }
+            f[i] = xt;
+            if (!(i == 24 && half)) mx = fmaxf(mx, xt);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+#pragma unroll
+        for (int i = 0; i < 25; ++i) f[i] = shift_exp_f(f[i] - mx, x0r, nx0, 15);
+        // torch-order row sum (n = 49), lane-local partials for l = 4*half + e
+        float pl[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pl[e] = ((((f[e] + f[16 + e]) + f[20 + e]) + f[4 + e]) + f[8 + e]) + f[12 + e];
+        float fin = f[24];                                    // x[48] (half 0)
+        fin = (((fin + pl[0]) + pl[1]) + pl[2]) + pl[3];
+        const float lo = __shfl(fin, l31);                    // half 0's partial
+        const float hi = (((lo + pl[0]) + pl[1]) + pl[2]) + pl[3];   // meaningful on half 1
+        const float S = __shfl(hi, l31 + 32);
+        const float F16 = recip_factor(S) * 5.9604644775390625e-08f;   // * 2^-24 (exact scaling)
+        // probabilities (0..128) -> B fragments P - 64 in the lane's own key order
+        v4i pf[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                unsigned word = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = w * 4 + e, i = kt ? 16 + r : r;
+                    int P = 64;                                // padding keys: P - 64 = 0 ... V rows there are 0 anyway
+                    if (kt == 0 || r < 8 || (r == 8 && !half)) P = (int)floorf(f[i < 25 ? i : 24] * F16);
+                    word |= (unsigned)((P - 64) & 0xff) << (8 * e);
+                }
+                pf[kt][w] = (int)word;
+            }
+        v16i_sw o;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = 0;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            o = __builtin_amdgcn_mfma_i32_32x32x32_i8(vf[kt], pf[kt], o, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_i32_32x32x32_i8(vf[kt], c64, o, 0, 0, 0);
+        }
+        // O^T[d][query]: lane = query, register quad g -> d = 8g + 4*half + (0..3)
+        unsigned W[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            int ob[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                ob[e] = min(max(__double2loint((double)o[g * 4 + e] * c_pv + 6755399441055744.0), -128), 127);
+            unsigned w01 = __builtin_amdgcn_perm((unsigned)ob[1], (unsigned)ob[0], 0x0c0c0400u);
+            unsigned w23 = __builtin_amdgcn_perm((unsigned)ob[3], (unsigned)ob[2], 0x0c0c0400u);
+            W[g] = __builtin_amdgcn_perm(w23, w01, 0x05040100u);
+        }
+        auto s02 = __builtin_amdgcn_permlane32_swap(W[0], W[2], false, false);
+        auto s13 = __builtin_amdgcn_permlane32_swap(W[1], W[3], false, false);
+        const v4i outv = {(int)s02[0], (int)s02[1], (int)s13[0], (int)s13[1]};   // d = 16*half .. +16
+        if (qlive) *reinterpret_cast<v4i *>(p.ctx + tok_off(q) * C + head * 32 + half * 16) = outv;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// PatchMerging gather (swin_quant.py:336-342): x [B, R, R, C] -> [B, R/2, R/2, 4C] with the channel
+// blocks ordered (0::2,0::2), (1::2,0::2), (0::2,1::2), (1::2,1::2).  IN = int8 or int16 elements
+// (after the first merge the stream is 8-bit); output int16 for the LayerNorm that follows.
+template <typename IN>
+__global__ __launch_bounds__(256) void patch_merge_gather_kernel(const IN *__restrict__ x, int B, int R, int C,
+                                                                 int16_t *__restrict__ out) {
+    // one thread per 8 consecutive output channels (C % 8 == 0: they come from one contiguous input run)
+    const int R2 = R / 2, C8 = C / 8;
+    const long long total = (long long)B * R2 * R2 * 4 * C8;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c8 = (int)(i % (4 * C8));
+        const long long t = i / (4 * C8);
+        const int xo = (int)(t % R2), yo = (int)((t / R2) % R2), b = (int)(t / ((long long)R2 * R2));
+        const int blk = c8 / C8, c = (c8 - blk * C8) * 8;
+        const int y = 2 * yo + (blk & 1), xx = 2 * xo + (blk >> 1);
+        const IN *src = x + (((long long)b * R + y) * R + xx) * C + c;
+        v8s o;
+        if (sizeof(IN) == 2) {
+            o = *reinterpret_cast<const v8s *>(src);
+        } else {
+            const v2i w = *reinterpret_cast<const v2i *>(src);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (short)(int8_t)(w[e >> 2] >> (8 * (e & 3)));
+        }
+        *reinterpret_cast<v8s *>(out + i * 8) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void widen_i8_i16_kernel(const int8_t *__restrict__ x, int16_t *__restrict__ out,
+                                                           long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        out[i] = (int16_t)x[i];
 }

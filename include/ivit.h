@@ -124,6 +124,9 @@ int ivit_attention_fused(ivit_handle h, const int8_t *q, const int8_t *k, const 
 int ivit_requant_i32(ivit_handle h, const int32_t *z, const ivit_dyadic *dy, int nch,
                      const int32_t *z_id, const ivit_dyadic *dy_id, int bits, void *out,
                      int64_t rows, int C);
+int ivit_requant_i16(ivit_handle h, const int16_t *z, const ivit_dyadic *dy, int nch,
+                     const int32_t *z_id, const ivit_dyadic *dy_id, int bits, void *out,
+                     int64_t rows, int C);
 int ivit_requant_f32(ivit_handle h, const float *z, const ivit_dyadic *dy, int nch,
                      const int32_t *z_id, const ivit_dyadic *dy_id, int bits, void *out,
                      int64_t rows, int C);
@@ -256,6 +259,25 @@ int ivit_avgpool_requant(ivit_handle h, const int8_t *x, int B, int L, int C, iv
  * ivit_layernorm otherwise.                                                                */
 int ivit_layernorm_tokenorder(ivit_handle h, const int16_t *x, int64_t rows, int C, float scale,
                               const float *bias_int, const float *sc, int tokens_per_image, float *z);
+
+/* the same with the per-channel QuantAct(8) that follows fused in (out8 int8 [rows, C])         */
+int ivit_layernorm_tokenorder_requant(ivit_handle h, const int16_t *x, int64_t rows, int C, float scale,
+                                      const float *bias_int, const float *sc, const ivit_dyadic *dy,
+                                      int tokens_per_image, int8_t *out8);
+/* Fused windowed attention: everything of WindowAttention.forward (swin_quant.py:121-169) between
+ * the qkv QuantAct and proj — q.k^T*scale -> qact_attn1 -> (+ relative position bias) qact2 ->
+ * Shiftmax 8 bit on attn (+ shift mask, :151-156) -> attn.v -> qact3 — including torch.roll,
+ * window_partition and their inverses (swin_quant.py:18-50, 268-287) as index arithmetic.
+ * qkv int8 [B, R, R, 3, heads, dh] in natural token order; ctx int8 [B, R*R, heads*dh] natural order.
+ * relb int16 [heads, 49, 49] = rq(quantised bias table gathered by relative_position_index,
+ * dy(qact_table -> qact2)); dy_a = dy(qact_attn1 -> qact2).  Built for window 7, dh 32.       */
+int ivit_window_attention_fused(ivit_handle h, const int8_t *qkv, ivit_dyadic dy_qk, ivit_dyadic dy_a,
+                                const int16_t *relb, float s_softmax, ivit_dyadic dy_pv, int8_t *ctx,
+                                int B, int R, int window, int shift, int heads, int dh);
+/* PatchMerging's 2x2 gather (swin_quant.py:336-342): x [B,R,R,C] (in_bits 8 or 16) ->
+ * int16 [B, (R/2)^2, 4C], channel blocks in the reference's torch.cat order.                  */
+int ivit_patch_merge_gather(ivit_handle h, const void *x, int in_bits, int B, int R, int C, int16_t *out);
+int ivit_widen_i8_i16(ivit_handle h, const int8_t *x, int16_t *out, int64_t n);
 
 /* ---- diagnostics (used by the parity tests only) ------------------------------------
  * q_ieee = n / d (compiler's correctly-rounded division) and q_lean = the hoisted-reciprocal

@@ -447,3 +447,24 @@ def test_swin_operator_surface_golden(fname):
         assert np.array_equal(got.reshape(ref.shape).astype(np.float64), ref.astype(np.float64)), name
     assert np.array_equal(acc.cpu().numpy(), g["logits_int"])
     assert np.array_equal(scale.numpy(), g["logits_scale"])
+
+
+# ---------------------------------------------------------------- Swin engine (fused windowed attention)
+@pytest.mark.parametrize("fname", ["micro_swin_b2.npz", "swin_tiny_b1.npz"])
+def test_swin_engine_golden_logits(fname):
+    """SwinEngine (natural-order activations, ivit_window_attention_fused) reproduces the reference's
+    int32 logits; on the micro model also against the CPU oracle for a fresh batch."""
+    from ivit_amd.swin_engine import SwinEngine
+    g = load_golden(fname)
+    cfg = iv.SWIN_CONFIGS[str(g["cfg_name"])]
+    w = iv.make_swin_weights(cfg, int(g["seed"]))
+    eng = SwinEngine(cfg, w, golden_scales(g))
+    imgs = iv.make_images_int8(cfg, int(g["batch"]), int(g["images_seed"]))
+    logits = eng.forward(dev(imgs)).cpu().numpy()
+    assert np.array_equal(logits, g["logits_int"])
+    assert np.array_equal(eng.head_scale, g["logits_scale"])
+    if fname.startswith("micro"):
+        from oracle import oracle as orc
+        imgs2 = iv.make_images_int8(cfg, 5, seed=123)
+        ref, _ = orc.OracleSwin(cfg, w, golden_scales(g)).forward(imgs2)
+        assert np.array_equal(eng.forward(dev(imgs2)).cpu().numpy(), ref)
