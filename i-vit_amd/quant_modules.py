@@ -177,10 +177,45 @@ class QuantAct(nn.Module):
         """scale from a calibrated range exactly like quant_utils.py:51-69"""
         self.set_scale(fz.symmetric_scale(min_val, max_val, self.activation_bit))
 
+    @torch.no_grad()
+    def quantize_param(self, param):
+        """input branch applied to a float PARAMETER on the host (pos_embed through qact_pos,
+        vit_quant.py:264): calibrates from the parameter when running_stat, returns float64 integers."""
+        p = param.detach().cpu().float()
+        if self.running_stat:
+            self._collect_range(p, None, None, None)
+        s = np.float32(self.act_scaling_factor.reshape(-1)[0].item())
+        if not s > 0:
+            raise ValueError("QuantAct has no scale: load act_scaling_factor or calibrate first")
+        return fz.quantize(p.numpy(), s, self.activation_bit, False)
+
+    @torch.no_grad()
+    def _collect_range(self, x, s_pre, identity, s_id):
+        """calibration (reference quant_modules.py:170-192): track min/max of the fp32 activation this
+        QuantAct sees — fl(x_int * s_pre) (+ fl(id_int * s_id)) — with the reference's momentum rule,
+        then its scale (quant_utils.py:51-69).  Range statistics are torch reductions on the device;
+        they run in calibration only, never on the frozen inference path."""
+        if s_pre is None:
+            X = x.float()
+        else:
+            X = x.float() * torch.as_tensor(_f32(s_pre), device=x.device)
+            if identity is not None:
+                X = identity.float() * torch.as_tensor(_f32(s_id), device=x.device) + X
+        cur_min = np.float32(X.min().item())
+        cur_max = np.float32(X.max().item())
+        mn, mx = np.float32(self.min_val.reshape(-1)[0].item()), np.float32(self.max_val.reshape(-1)[0].item())
+        if mn == mx:
+            mn, mx = cur_min, cur_max
+        else:
+            mom = np.float32(self.act_range_momentum)
+            mn = np.float32(np.float32(mn * mom) + np.float32(cur_min * np.float32(1 - self.act_range_momentum)))
+            mx = np.float32(np.float32(mx * mom) + np.float32(cur_max * np.float32(1 - self.act_range_momentum)))
+        self.min_val, self.max_val = torch.tensor([mn]), torch.tensor([mx])
+        self.set_range(mn, mx)
+
     def forward(self, x, pre_act_scaling_factor=None, identity=None, identity_scaling_factor=None):
         if self.running_stat:
-            raise NotImplementedError("activation-range calibration (running_stat=True) is host-side future "
-                                      "work (SURVEY.md §8f N1): call fix()/freeze_model after setting scales")
+            self._collect_range(x, pre_act_scaling_factor, identity, identity_scaling_factor)
         s_out = np.float32(self.act_scaling_factor.reshape(-1)[0].item())
         if not s_out > 0:
             raise ValueError("QuantAct has no scale: load act_scaling_factor or call set_scale()")

@@ -236,6 +236,20 @@ class SwinEngine:
         call("ivit_linear_i8", P(ws["pool"]), self.ptr("head.w"), self.ptr("head.b"), P(ws["logits"]), B, cfg.num_classes, C)
         return ws["logits"]
 
+    def capture(self, images):
+        """hipGraph of one forward on fixed buffers (every C-ABI call is capturable: nothing allocates or
+        synchronises).  Returns a callable that replays it and returns the logits tensor."""
+        self.forward(images)                    # allocates the workspace outside the capture
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = self.forward(images)
+
+        def replay():
+            g.replay()
+            return out
+        return replay
+
     def _ln(self, x16, M, C, s_in, name, L, token_order, out8):
         P = lambda t: _P(t.data_ptr())
         if token_order:

@@ -152,9 +152,7 @@ class VisionTransformer(nn.Module):
         cls_t = torch.from_numpy(cls).to(x.device).reshape(1, 1, -1).expand(B, -1, -1)
         z = torch.cat((cls_t, x.to(torch.int32)), dim=1)
         # position embedding: a parameter, quantised on the host once (qact_pos, 16 bit)
-        from . import freeze as fz
-        s_pos = np.float32(self.qact_pos.act_scaling_factor.reshape(-1)[0].item())
-        pos = fz.quantize(self.pos_embed.detach().cpu().numpy()[0], s_pos, 16, False).astype(np.int32)
+        pos = self.qact_pos.quantize_param(self.pos_embed[0]).astype(np.int32)
         x_pos = torch.from_numpy(pos).to(x.device).unsqueeze(0)
         x, s = self.qact1(z, s, x_pos, self.qact_pos.act_scaling_factor)
         for blk in self.blocks:

@@ -414,8 +414,9 @@ def test_operator_error_behaviour():
     lin = iv.QuantLinear(64, 16, per_channel=False)
     with pytest.raises(Exception):
         lin(torch.zeros(4, 64, dtype=torch.int8, device="cuda"), torch.tensor(0.1))
-    act = iv.QuantAct()   # running_stat=True: calibration is not on the device path
-    with pytest.raises(NotImplementedError):
+    act = iv.QuantAct()
+    act.fix()             # frozen without ever having seen a range or a loaded scale
+    with pytest.raises(ValueError):
         act(torch.zeros(4, 8, dtype=torch.int32, device="cuda"), torch.tensor(0.1))
 
 
@@ -468,3 +469,55 @@ def test_swin_engine_golden_logits(fname):
         imgs2 = iv.make_images_int8(cfg, 5, seed=123)
         ref, _ = orc.OracleSwin(cfg, w, golden_scales(g)).forward(imgs2)
         assert np.array_equal(eng.forward(dev(imgs2)).cpu().numpy(), ref)
+
+
+# ---------------------------------------------------------------- calibration
+CALIB_BATCH = {"micro_vit_b2.npz": 4, "micro_vit2h_b3.npz": 4, "deit_tiny_b1.npz": 2, "micro_swin_b2.npz": 4}
+
+
+@pytest.mark.parametrize("fname", sorted(CALIB_BATCH))
+def test_calibration_reproduces_reference_scales(fname):
+    """running_stat=True branch of QuantAct (quant_modules.py:170-192): one forward of the seeded fp32
+    calibration batch through the operator surface, then freeze_model, yields the activation scales the
+    reference's own calibration produced (stored in the fixtures).
+
+    Bit-equality holds until the first site whose maximum falls on an element where the reference's fp32
+    fake-quant value differs by one ulp from fl(integer * scale): it carries fl(fl(Q*s)/s) != Q into
+    x_int * sigmoid_int and F.linear, and its attn.v is an fp32 bmm that is inexact above 2^24
+    (SURVEY.md A).  From there the min/max procedure is chaotic at the 1e-3 level (one flipped rounding
+    tie moves a later maximum by a whole quantisation step) — for the reference itself as much as for
+    this build.  Pinned: micro_vit bit-equal with identical logits; every fixture within 2 % per site
+    and bit-equal on at least the sites before the first attention / GELU output."""
+    g = load_golden(fname)
+    name = str(g["cfg_name"])
+    if name in iv.SWIN_CONFIGS:
+        from ivit_amd.swin_quant import SwinTransformer
+        cfg = iv.SWIN_CONFIGS[name]
+        m = SwinTransformer(img_size=cfg.img_size, patch_size=cfg.patch_size, in_chans=cfg.in_chans,
+                            num_classes=cfg.num_classes, embed_dim=cfg.embed_dim, depths=cfg.depths,
+                            num_heads=cfg.num_heads, window_size=cfg.window_size, mlp_ratio=cfg.mlp_ratio)
+        m.load_float_weights(iv.make_swin_weights(cfg, int(g["seed"])))
+    else:
+        cfg = iv.CONFIGS[name]
+        m = iv.VisionTransformer(img_size=cfg.img_size, patch_size=cfg.patch_size, num_classes=cfg.num_classes,
+                                 embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads, mlp_ratio=4)
+        m.load_float_weights(iv.make_vit_weights(cfg, int(g["seed"])))
+    calib = iv.make_calibration_batch(cfg, CALIB_BATCH[fname])
+    with torch.no_grad():
+        m(dev(calib))
+    iv.freeze_model(m)
+    ref = golden_scales(g)
+    got = {k: np.float32(mod.act_scaling_factor.reshape(-1)[0].item()) for k, mod in m.named_modules()
+           if type(mod) is iv.QuantAct}
+    assert all(k in got for k in ref), set(ref) - set(got)
+    bad = {k: (float(got[k]), float(v)) for k, v in ref.items() if got[k] != v and v > 0}
+    if fname == "micro_vit_b2.npz":
+        assert not bad, bad
+        imgs = iv.make_images_int8(cfg, int(g["batch"]), int(g["images_seed"]))
+        with torch.no_grad():
+            acc, _ = m(dev(imgs))
+        assert np.array_equal(acc.cpu().numpy(), g["logits_int"])
+    first = ("qact_input", "patch_embed.qact", "patch_embed.qact_before_norm", "qact_pos", "qact1", "blocks.0.qact1",
+             "blocks.0.attn.qact1", "blocks.0.attn.qact_attn1", "layers.0.blocks.0.qact1", "layers.0.blocks.0.attn.qact1")
+    assert not [k for k in bad if k in first], bad
+    assert all(abs(a - b) <= 0.02 * b for a, b in bad.values()), bad
