@@ -21,6 +21,12 @@ _LAZY = {
     "vit_base_patch16_224": ("vit_quant", "vit_base_patch16_224"),
     "vit_large_patch16_224": ("vit_quant", "vit_large_patch16_224"),
     "freeze_model": ("model_utils", "freeze_model"), "unfreeze_model": ("model_utils", "unfreeze_model"),
+    "SwinTransformer": ("swin_quant", "SwinTransformer"),
+    "swin_tiny_patch4_window7_224": ("swin_quant", "swin_tiny_patch4_window7_224"),
+    "swin_small_patch4_window7_224": ("swin_quant", "swin_small_patch4_window7_224"),
+    "swin_base_patch4_window7_224": ("swin_quant", "swin_base_patch4_window7_224"),
+    "SwinEngine": ("swin_engine", "SwinEngine"),
+    "load_reference_state_dict": ("checkpoint", "load_reference_state_dict"),
 }
 
 
