@@ -79,7 +79,7 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 4 : (G2_NSTAGE128 == 2 ? 4 : 3)
     constexpr int G2_BM = BM, G2_STAGE = Cf::STAGE, G2_SMEM = Cf::SMEM, NT = Cf::THREADS;
     constexpr int NLOADS = 2 + Cf::B_PER_THREAD;       // DMA loads per thread per K step
     constexpr int NS = Cf::NSTAGE;                     // ring depth: loads run NS-1 steps ahead
-    __shared__ __attribute__((aligned(16))) char smem[G2_SMEM + 1536];
+    __shared__ __attribute__((aligned(16))) char smem[G2_SMEM + 1536 + 512];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, half = lane >> 5;
 
@@ -102,12 +102,16 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 4 : (G2_NSTAGE128 == 2 ? 4 : 3)
     // K-loop barriers order the write): c[n] = m*2^-e (exact in fp64), bias[n]
     double *sC = reinterpret_cast<double *>(smem + G2_SMEM);
     int *sBias = reinterpret_cast<int *>(smem + G2_SMEM + 1024);
+    int *sUnsafe = reinterpret_cast<int *>(smem + G2_SMEM + 1536);   // [G2_BN] per-channel flags
     if (tid < G2_BN) {
         const int ch = col0 + tid;
         const bool in = ch < p.N;
         const double cv = in ? p.dy_ch[ch].m * p.dy_ch[ch].r : 0.0;
+        const int bs = (in && p.bias) ? p.bias[ch] : 0;
         sC[tid] = cv;
-        sBias[tid] = (in && p.bias) ? p.bias[ch] : 0;
+        sBias[tid] = bs;
+        // magic-number rounding in the epilogue needs |(acc + bias) * c| < 2^31; |acc| <= K * 2^14
+        sUnsafe[tid] = !(fabs(cv) * ((double)p.K * 16384.0 + fabs((double)bs)) < 2147483000.0);
     }
 
     // acc[i][j]: C^T sub-tiles — lane holds token (lane&31) of m-tile i and, per register
@@ -167,46 +171,29 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 4 : (G2_NSTAGE128 == 2 ? 4 : 3)
     constexpr bool OUT8 = (EPI == EPI_RQ8_CH || EPI == EPI_QKV);
     constexpr int OLO = OUT8 ? -128 : -32768, OHI = OUT8 ? 127 : 32767;
     // ---- phase 1: requant + pack 4 channels per lane -> staged tile [token][channel].
-    // Per 4-channel group the wave takes rq_fast when every |acc + bias| < 2^22 and |c| < 2^9
-    // (wave-uniform vote), else the 3-op reference form.
+    // rne(fl64(z*c)) as loint(fl64(z*c) + 1.5*2^52): the reference's two roundings (quant_utils.py:229-231),
+    // valid while |z*c| < 2^31 — checked per channel when the constants were staged; else the rint form.
+    const bool fastrq = !__any(sUnsafe[wn * 64 + lane] != 0);   // this wave's 64 channels
+    auto phase1 = [&](auto use_fast) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int nl = wn * 64 + j * 32 + g * 8 + half * 4;
-            double c[4];
-            int z[2][4];
-            bool ok = true;
+            for (int g = 0; g < 4; ++g) {
+                const int nl = wn * 64 + j * 32 + g * 8 + half * 4;
+                double c[4];
+                int bs[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                c[e] = sC[nl + e];
-                const int bs = sBias[nl + e];
-                ok = ok && (fabs(c[e]) < RQ_FAST_CLIM);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    z[i][e] = acc[i][j][g * 4 + e] + bs;
-                    ok = ok && ((unsigned)(z[i][e] + RQ_FAST_ZLIM) < (unsigned)(2 * RQ_FAST_ZLIM));
-                }
-            }
-            if (p.dbg == 3) {   // ablation: no requant math, just stage the low bytes
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int ml = wm * 64 + i * 32 + (lane & 31);
-                    if (OUT8) *reinterpret_cast<unsigned *>(smem + ml * G2_LD8 + nl) = (unsigned)(z[i][0] ^ z[i][1] ^ z[i][2] ^ z[i][3]);
-                    else *reinterpret_cast<v2i *>(smem + ml * G2_LD16 + nl * 2) = v2i{z[i][0] ^ z[i][1], z[i][2] ^ z[i][3]};
-                }
-                continue;
-            }
-            const bool fast = __all(ok);
-            auto emit = [&](auto use_fast) {
+                for (int e = 0; e < 4; ++e) { c[e] = sC[nl + e]; bs[e] = sBias[nl + e]; }
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int ml = wm * 64 + i * 32 + (lane & 31);
                     int o[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const int v = decltype(use_fast)::value ? rq_fast(z[i][e], c[e])
-                                                                : (int)__builtin_rint((double)z[i][e] * c[e]);
+                        const int z = acc[i][j][g * 4 + e] + bs[e];
+                        if (p.dbg == 3) { o[e] = z; continue; }   // ablation: no requant math
+                        const double t = (double)z * c[e];
+                        const int v = decltype(use_fast)::value ? __double2loint(t + 6755399441055744.0) : (int)__builtin_rint(t);
                         o[e] = min(max(v, OLO), OHI);
                     }
                     if (OUT8) {
@@ -219,10 +206,10 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 4 : (G2_NSTAGE128 == 2 ? 4 : 3)
                         *reinterpret_cast<v2i *>(smem + ml * G2_LD16 + nl * 2) = w;
                     }
                 }
-            };
-            if (fast) emit(std::true_type{});
-            else emit(std::false_type{});
-        }
+            }
+    };
+    if (fastrq) phase1(std::true_type{});
+    else phase1(std::false_type{});
     __syncthreads();
     if (p.dbg == 2) return;   // ablation: no phase 2 (no global stores)
 

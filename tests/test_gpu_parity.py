@@ -262,6 +262,33 @@ def test_bmm_nt_u16i8_full_range(H, nb, M, N, K):
     assert np.array_equal(C.cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (257, 136, 64)])
+def test_linear_requant_saturating_and_tie_channels(H, M, N, K):
+    """requant factors far outside the magic-number range (|z*c| >= 2^31: the kernel must fall back to the
+    saturating rint form for those column blocks), int32-scale biases, and factors of exactly 0.5 / 1.5
+    (every odd accumulator is a rounding tie) — all against the oracle."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(7 * M + N + K)
+    x = rng.integers(-128, 128, (M, K), dtype=np.int8)
+    w = rng.integers(-128, 128, (N, K), dtype=np.int8)
+    b = rng.integers(-2 ** 30, 2 ** 30, N).astype(np.int32)
+    b[::3] = rng.integers(-2 ** 10, 2 ** 10, len(b[::3]))
+    acc = orc.linear_i8(x, w, b)
+    s_out = np.float32(1.0)
+    s_pre = np.full(N, 1e-5, np.float32)
+    s_pre[0::4] = 0.5            # exact ties
+    s_pre[1::4] = 1.5
+    s_pre[2::8] = 3.0e4          # |z*c| up to ~2^45: saturates, must not wrap
+    s_pre[130:] = 1e-6           # second column block: small factors only where the biases are small
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    for bits in (8, 16):
+        d = iv.freeze.dyadic(s_pre, s_out)
+        out = torch.empty(M, N, dtype={8: torch.int8, 16: torch.int16}[bits], device="cuda")
+        H.call("ivit_linear_i8_requant", P(xd), P(wd), P(bd), P(dev(d)), bits, P(out), M, N, K)
+        ref = orc.requant(acc, orc.dyadic(s_pre, s_out), bits)
+        assert np.array_equal(out.cpu().numpy().astype(np.int32), ref), (bits, M, N, K)
+
+
 @pytest.mark.parametrize("B,Hh,T", [(2, 3, 197), (1, 2, 17), (3, 1, 64), (1, 2, 577), (2, 2, 200), (1, 1, 250)])
 def test_fused_attention_equals_unfused_chain(H, B, Hh, T):
     """fused kernel == qk_requant + shiftmax + pv_requant (themselves golden-pinned)."""
