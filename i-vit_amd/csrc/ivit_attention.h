@@ -45,7 +45,10 @@ struct AttCfg {
     static constexpr int SMEM = SK_BYTES + SV_BYTES + SO_BYTES + 256 + 1024;
 };
 
-template <int NB, bool FAST>   // FAST: |c_qk|, |c_pv| < 2^9 (host-checked) -> rq_fast is exact
+// FAST: |c_qk|, |c_pv| < 2^9 (host-checked) -> rq_fast is exact.  TT: the token count when it is known at
+// compile time (197 / 577: the 224- and 384-pixel ViTs), 0 = run-time p.T.  With TT fixed every tile-validity
+// test folds away; the generic form keeps ~70 loop-invariant lane masks alive and spills SGPRs in the hot loop.
+template <int NB, bool FAST, int TT = 0>
 __global__ __launch_bounds__(ATT_WAVES * 64) void attn_fused_kernel(AttnArgs p) {
     using C = AttCfg<NB>;
     extern __shared__ __attribute__((aligned(16))) char dsmem[];
@@ -57,7 +60,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void attn_fused_kernel(AttnArgs p) 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
-    const int T = p.T;
+    const int T = TT ? TT : p.T;
     const int8_t *qg = p.q + (long long)bh * T * 64;
     const int8_t *kg = p.k + (long long)bh * T * 64;
     const int8_t *vg = p.vt + (long long)bh * 64 * p.ldv;

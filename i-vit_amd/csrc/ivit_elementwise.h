@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void layernorm16_kernel(const int16_t *__restr
         cSc[c] = scv;
         cY[c] = rcp_prepare(scv).y;
         cB[c] = bias_int[c];
-        cC[c] = dy[c].m * dy[c].r;
+        cC[(c & 7) * (C >> 3) + (c >> 3)] = dy[c].m * dy[c].r;   // [e][chunk]: a lane group reads consecutive doubles
     }
     __syncthreads();
     const int sub = tid & 15, slot = tid >> 4;
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void layernorm16_kernel(const int16_t *__restr
                 const float yi = floorf((y * F) * 0.5f);
                 const float o = yi + bi;
                 const float zz = rintf(lean_div(o * rc.d, rc));
-                const int v = rq_c((double)zz, cC[c * 8 + e], -128, 127);
+                const int v = rq_c((double)zz, cC[e * nch8 + c], -128, 127);
                 pk[e >> 2] |= ((unsigned)v & 0xffu) << (8 * (e & 3));
             }
             if (live) *reinterpret_cast<v2i *>(out + row * C + c * 8) = v2i{(int)pk[0], (int)pk[1]};

@@ -239,15 +239,15 @@ int ivit_attn_pv_requant(ivit_handle h, const uint16_t *p, const int8_t *vt, ivi
 
 }  // extern "C"
 
-template <int NB, bool FAST>
+template <int NB, bool FAST, int TT = 0>
 static int launch_attn2(ivit_handle h, const AttnArgs &a, int BH) {
     const size_t lds = AttCfg<NB>::SMEM;
     if (lds > 65536) {
-        hipError_t e = hipFuncSetAttribute((const void *)attn_fused_kernel<NB, FAST>,
+        hipError_t e = hipFuncSetAttribute((const void *)attn_fused_kernel<NB, FAST, TT>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { snprintf(h->err, sizeof(h->err), "attn attr: %s", hipGetErrorString(e)); return IVIT_ERR_HIP; }
     }
-    attn_fused_kernel<NB, FAST><<<BH, ATT_WAVES * 64, lds, h->stream>>>(a);
+    attn_fused_kernel<NB, FAST, TT><<<BH, ATT_WAVES * 64, lds, h->stream>>>(a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(h->err, sizeof(h->err), "attn launch: %s", hipGetErrorString(e)); return IVIT_ERR_HIP; }
     return IVIT_OK;
@@ -257,6 +257,12 @@ template <int NB>
 static int launch_attn(ivit_handle h, const AttnArgs &a, int BH) {
     const double cq = a.dy_qk.m * a.dy_qk.r, cp = a.dy_pv.m * a.dy_pv.r;
     const bool fast = (cq < 512.0 && cq > -512.0 && cp < 512.0 && cp > -512.0);
+    static int dyn_t = -1;   // IVIT_ATTN_DYNAMIC_T=1: never use the fixed-T specialisations (A/B, tests)
+    if (dyn_t < 0) { const char *e = getenv("IVIT_ATTN_DYNAMIC_T"); dyn_t = e ? atoi(e) : 0; }
+    if (fast && !dyn_t) {
+        if (NB == 4 && a.T == 197) return launch_attn2<NB, true, 197>(h, a, BH);
+        if (NB == 10 && a.T == 577) return launch_attn2<NB, true, 577>(h, a, BH);
+    }
     return fast ? launch_attn2<NB, true>(h, a, BH) : launch_attn2<NB, false>(h, a, BH);
 }
 

@@ -64,3 +64,21 @@ if pm:
                    f"act_lds {c.get('SQ_ACTIVE_INST_LDS',0):.3g}")
         if l2:
             print(l2)
+
+# ---- HBM traffic per QuantLinear GEMM launch -> pmc_traffic.json (feeds bench.py roofline.traffic)
+import json
+gemm = {k: v for k, v in pm.items() if k.startswith("gemm_")}
+if gemm and all("FETCH_SIZE" in v and "WRITE_SIZE" in v for v in gemm.values()):
+    per, tot_b, tot_n = {}, 0.0, 0
+    for k, v in gemm.items():
+        n = len(v["FETCH_SIZE"])
+        fb = sum(v["FETCH_SIZE"]) / n * 1024 * 2
+        wb = sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"]) * 1024
+        per[k] = {"launches": n, "fetch_MB_x2": round(fb / 1e6, 2), "write_MB": round(wb / 1e6, 2)}
+        tot_b += (fb + wb) * n
+        tot_n += n
+    js = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes; FETCH doubled per MI355X_MICROARCH.md HBM section)",
+          "command": "python bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile-steps 0 --streams 1 --graph 0",
+          "per_kernel": per, "avg_bytes_per_launch": tot_b / tot_n}
+    json.dump(js, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
+    print("\npmc_traffic.json: avg HBM bytes per GEMM launch %.1f MB" % (tot_b / tot_n / 1e6))
