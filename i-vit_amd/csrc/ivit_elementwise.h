@@ -164,12 +164,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const int16_t *__restric
 // iteration leaves its loop as soon as every row of the wavefront sits on a fixed point
 // (k' == k implies all later iterates equal k, so the early exit is exact).
 #define LN_RITER 4
-__global__ __launch_bounds__(256) void layernorm16_kernel(const int16_t *__restrict__ x, long long rows, int C,
+template <int CC>   // CC: channel count when known at compile time (loops unroll, no bound tests), 0 = run-time
+__global__ __launch_bounds__(256) void layernorm16_kernel(const int16_t *__restrict__ x, long long rows, int C_rt,
                                                           long long row_stride, float s,
                                                           const float *__restrict__ bias_int,
                                                           const float *__restrict__ sc,
                                                           const ivit_dyadic *__restrict__ dy,
                                                           int8_t *__restrict__ out) {
+    const int C = CC ? CC : C_rt;
     extern __shared__ __attribute__((aligned(16))) char dsmem[];
     const int LD = C + 16;                                   // row stride (floats): skews rows by 16 banks
     float *xrows = reinterpret_cast<float *>(dsmem);          // [16][LD]

@@ -417,11 +417,20 @@ int ivit_layernorm_requant(ivit_handle h, const int16_t *x, int64_t rows, int C,
         static int ln_old = -1;
         if (ln_old < 0) { const char *e = getenv("IVIT_LN_OLD"); ln_old = e ? atoi(e) : 0; }
         if (lds16 <= 150 * 1024 && !ln_old) {
-            int st16 = set_dyn_lds(h, (const void *)layernorm16_kernel, lds16);
-            if (st16) return st16;
             const long long per_block = 16 * LN_RITER;
-            layernorm16_kernel<<<(unsigned)((rows + per_block - 1) / per_block), 256, lds16, h->stream>>>(
-                x, rows, C, row_stride, scale, bias_int, sc, dy_ch, out8);
+            const unsigned grid = (unsigned)((rows + per_block - 1) / per_block);
+#define LN16_LAUNCH(CC)                                                                                   \
+            do {                                                                                          \
+                int st16 = set_dyn_lds(h, (const void *)layernorm16_kernel<CC>, lds16);                   \
+                if (st16) return st16;                                                                    \
+                layernorm16_kernel<CC><<<grid, 256, lds16, h->stream>>>(x, rows, C, row_stride, scale,    \
+                                                                       bias_int, sc, dy_ch, out8);       \
+            } while (0)
+            if (C == 384) LN16_LAUNCH(384);          // DeiT-S / Swin stage 2
+            else if (C == 768) LN16_LAUNCH(768);     // DeiT-B, ViT-B / Swin stage 3
+            else if (C == 192) LN16_LAUNCH(192);     // DeiT-T / Swin stage 1
+            else LN16_LAUNCH(0);
+#undef LN16_LAUNCH
             LAUNCH_CHECK(h);
             return IVIT_OK;
         }
