@@ -94,7 +94,8 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 4 : (G2_NSTAGE128 == 2 ? 4 : 3)
     const int8_t *A = reinterpret_cast<const int8_t *>(p.A);
     const int8_t *B = p.B;
 
-    const int nk = p.K / G2_BK;
+    const int Kdim = p.K;
+    const int nk = Kdim / G2_BK;
     g2_issue<BM>(A, B, p.lda, p.ldb, p.M, p.N, row0, col0, 0, smem, tid);
     if (NS == 3 && nk > 1) g2_issue<BM>(A, B, p.lda, p.ldb, p.M, p.N, row0, col0, G2_BK, smem + G2_STAGE, tid);
 
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 4 : (G2_NSTAGE128 == 2 ? 4 : 3)
         sC[tid] = cv;
         sBias[tid] = bs;
         // magic-number rounding in the epilogue needs |(acc + bias) * c| < 2^31; |acc| <= K * 2^14
-        sUnsafe[tid] = !(fabs(cv) * ((double)p.K * 16384.0 + fabs((double)bs)) < 2147483000.0);
+        sUnsafe[tid] = !(fabs(cv) * ((double)Kdim * 16384.0 + fabs((double)bs)) < 2147483000.0);
     }
 
     // acc[i][j]: C^T sub-tiles — lane holds token (lane&31) of m-tile i and, per register
@@ -127,11 +128,14 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 4 : (G2_NSTAGE128 == 2 ? 4 : 3)
     v4i a[2], b[2];
     for (int kt = 0; kt < nk; ++kt) {
         if (NS == 3 && kt + 1 < nk) {
-            if (NLOADS == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if (NLOADS == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
         } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         }
+        // lgkmcnt(0): a raw s_barrier does not wait for this wave's own LDS reads.  The fragment reads of the
+        // previous step must have RETURNED before any wave may start the DMA that overwrites their buffer —
+        // the scheduler is free to sink their first use (and with it the implicit wait) below the barrier.
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (kt + NS - 1 < nk)
@@ -281,6 +285,7 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 4 : (G2_NSTAGE128 == 2 ? 4 : 3)
             }
         }
     } else if (EPI == EPI_QKV) {
+        const float rcpT = 1.0f / (float)p.T;
         // rows-fastest mapping: a wave covers 64 consecutive tokens of one 16-channel chunk
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -292,7 +297,11 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 4 : (G2_NSTAGE128 == 2 ? 4 : 3)
                 v4i v = {lo[0], lo[1], hi[0], hi[1]};
                 int which = gcol / p.D, within = gcol - which * p.D;
                 int head = within / p.dh, d0 = within - head * p.dh;
-                int b = grow / p.T, t = grow - b * p.T;
+                // token -> (image, position): float reciprocal estimate + one correction step (grow < 2^23)
+                int b = (int)((float)grow * rcpT);
+                int t = grow - b * p.T;
+                if (t < 0) { --b; t += p.T; }
+                if (t >= p.T) { ++b; t -= p.T; }
                 long long bh = (long long)b * p.H + head;
                 if (which < 2) {
                     int8_t *dst = (which == 0 ? p.q : p.k) + (bh * p.T + t) * p.dh + d0;
