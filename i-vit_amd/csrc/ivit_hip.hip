@@ -429,6 +429,7 @@ int ivit_layernorm_requant(ivit_handle h, const int16_t *x, int64_t rows, int C,
             if (C == 384) LN16_LAUNCH(384);          // DeiT-S / Swin stage 2
             else if (C == 768) LN16_LAUNCH(768);     // DeiT-B, ViT-B / Swin stage 3
             else if (C == 192) LN16_LAUNCH(192);     // DeiT-T / Swin stage 1
+            else if (C == 1536) LN16_LAUNCH(1536);   // Swin PatchMerging before stage 3
             else LN16_LAUNCH(0);
 #undef LN16_LAUNCH
             LAUNCH_CHECK(h);
@@ -489,10 +490,15 @@ int ivit_layernorm_tokenorder_requant(ivit_handle h, const int16_t *x, int64_t r
     REQUIRE(h, x && bias_int && sc && dy && out8 && rows > 0 && C > 0 && scale > 0.f && tokens_per_image > 0, "bad arguments");
     const size_t lds = ((size_t)64 * (C + 1) + 3 * (size_t)C + 130) * sizeof(float) + (size_t)C * sizeof(double);
     REQUIRE(h, lds <= 160 * 1024, "C too large for LDS staging");
-    int st = set_dyn_lds(h, (const void *)layernorm_tokenorder_kernel<true>, lds);
-    if (st) return st;
-    layernorm_tokenorder_kernel<true><<<(unsigned)((rows + 63) / 64), 256, lds, h->stream>>>(
-        x, rows, C, scale, bias_int, sc, dy, tokens_per_image, out8);
+    if (C == 96) {          // Swin-T/S stage 0
+        layernorm_tokenorder_kernel<true, 96><<<(unsigned)((rows + 63) / 64), 256, lds, h->stream>>>(
+            x, rows, C, scale, bias_int, sc, dy, tokens_per_image, out8);
+    } else {
+        int st = set_dyn_lds(h, (const void *)layernorm_tokenorder_kernel<true, 0>, lds);
+        if (st) return st;
+        layernorm_tokenorder_kernel<true, 0><<<(unsigned)((rows + 63) / 64), 256, lds, h->stream>>>(
+            x, rows, C, scale, bias_int, sc, dy, tokens_per_image, out8);
+    }
     LAUNCH_CHECK(h);
     return IVIT_OK;
 }
@@ -503,9 +509,9 @@ int ivit_layernorm_tokenorder(ivit_handle h, const int16_t *x, int64_t rows, int
     REQUIRE(h, x && bias_int && sc && z && rows > 0 && C > 0 && scale > 0.f && tokens_per_image > 0, "bad arguments");
     const size_t lds = ((size_t)64 * (C + 1) + 3 * (size_t)C + 130) * sizeof(float) + (size_t)C * sizeof(double);
     REQUIRE(h, lds <= 160 * 1024, "C too large for LDS staging");
-    int st = set_dyn_lds(h, (const void *)layernorm_tokenorder_kernel<false>, lds);
+    int st = set_dyn_lds(h, (const void *)layernorm_tokenorder_kernel<false, 0>, lds);
     if (st) return st;
-    layernorm_tokenorder_kernel<false><<<(unsigned)((rows + 63) / 64), 256, lds, h->stream>>>(
+    layernorm_tokenorder_kernel<false, 0><<<(unsigned)((rows + 63) / 64), 256, lds, h->stream>>>(
         x, rows, C, scale, bias_int, sc, nullptr, tokens_per_image, z);
     LAUNCH_CHECK(h);
     return IVIT_OK;

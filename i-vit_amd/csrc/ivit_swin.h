@@ -123,12 +123,13 @@ __device__ __forceinline__ float strided_order_sum(const float *x, int n, bool i
 // 64 tokens per 256-thread block: the loads (with fl(fl(Q*s)/s)) and the normalise / requant / store pass
 // are spread over all threads; only the two order-sensitive sums and the integer square root of a token run
 // on one thread (wave 0, one token per lane).  Per-channel divisors use the hoisted reciprocal (lean_div).
-template <bool OUT8>
-__global__ __launch_bounds__(256) void layernorm_tokenorder_kernel(const int16_t *__restrict__ x, long long rows, int C,
+template <bool OUT8, int CC>   // CC: compile-time channel count (index arithmetic by constants), 0 = run-time
+__global__ __launch_bounds__(256) void layernorm_tokenorder_kernel(const int16_t *__restrict__ x, long long rows, int C_rt,
                                                                    float s, const float *__restrict__ bias_int,
                                                                    const float *__restrict__ sc,
                                                                    const ivit_dyadic *__restrict__ dy, int L,
                                                                    void *__restrict__ out) {
+    const int C = CC ? CC : C_rt;
     extern __shared__ __attribute__((aligned(16))) char dsmem[];
     const int LD = C + 1;
     float *tile = reinterpret_cast<float *>(dsmem);            // [64][C + 1]
