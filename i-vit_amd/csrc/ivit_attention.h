@@ -151,7 +151,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void attn_fused_kernel(AttnArgs p) 
             if (j < ntile) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float e = shift_exp_f(f[j][r] - mx, x0r, nx0, 15);
+                    float e = shift_exp_nonpos(f[j][r] - mx, x0r, nx0, 15);
                     f[j][r] = (j * 16 + 15 < T || j * 16 + g * 4 + r < T) ? e : 0.f;
                 }
             }
@@ -244,8 +244,9 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void attn_fused_kernel(AttnArgs p) 
                 const int j = kb * 4 + jj;
                 unsigned wl = 0, wh = 0xC0C0C0C0u;   // P = 0 -> hi = -64, lo = 0 (V is 0 there)
                 if (j < ntile) {
-                    unsigned P0 = (unsigned)(int)floorf(f[j][0] * F16), P1 = (unsigned)(int)floorf(f[j][1] * F16);
-                    unsigned P2 = (unsigned)(int)floorf(f[j][2] * F16), P3 = (unsigned)(int)floorf(f[j][3] * F16);
+                    // e*F16 >= 0: the float -> int conversion truncates, which IS the reference's floor
+                    unsigned P0 = (unsigned)(int)(f[j][0] * F16), P1 = (unsigned)(int)(f[j][1] * F16);
+                    unsigned P2 = (unsigned)(int)(f[j][2] * F16), P3 = (unsigned)(int)(f[j][3] * F16);
                     unsigned l01 = __builtin_amdgcn_perm(P1, P0, 0x0c0c0400u), l23 = __builtin_amdgcn_perm(P3, P2, 0x0c0c0400u);
                     wl = __builtin_amdgcn_perm(l23, l01, 0x05040100u);
                     unsigned h01 = __builtin_amdgcn_perm(P1 - 16256u, P0 - 16256u, 0x0c0c0501u);

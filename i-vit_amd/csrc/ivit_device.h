@@ -109,6 +109,18 @@ __device__ __forceinline__ float shift_exp_f(float x, RcpC x0, float nx0, int n)
     return fmaxf(e, 0.0f);
 }
 
+// Shiftmax only (x <= 0): the reference's final clamp(min=0) can never bind — t <= 0 and x0 <= -1 give
+// q >= 0, r = t - x0*q in (x0, 0] up to an ulp, so e = r/2 - x0 >= -x0/2 - ulp > 0 and floor(e * 2^(n-q)) >= 0.
+__device__ __forceinline__ float shift_exp_nonpos(float x, RcpC x0, float nx0, int n) {
+    float t = x + floorf(x * 0.5f);
+    t = t - floorf(x * 0.0625f);
+    t = fmaxf(t, nx0);
+    float q = floorf(lean_div(t, x0));
+    float r = __builtin_fmaf(-x0.d, q, t);
+    float e = __builtin_fmaf(r, 0.5f, -x0.d);
+    return floorf(ldexpf(e, n - (int)q));
+}
+
 // ---- fp32-faithful pieces ---------------------------------------------------
 // value a consumer of (Q, s) sees: fl(fl(Q*s)/s)   (quant_modules.py:204-206 then
 // :94/:359/:426/:484).  Not always equal to Q.

@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs p) {
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
 #pragma unroll
-        for (int i = 0; i < 25; ++i) f[i] = shift_exp_f(f[i] - mx, x0r, nx0, 15);
+        for (int i = 0; i < 25; ++i) f[i] = shift_exp_nonpos(f[i] - mx, x0r, nx0, 15);
         // torch-order row sum (n = 49), lane-local partials for l = 4*half + e
         float pl[4];
 #pragma unroll
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs p) {
                 for (int e = 0; e < 4; ++e) {
                     const int r = w * 4 + e, i = kt ? 16 + r : r;
                     int P = 64;                                // padding keys: P - 64 = 0 ... V rows there are 0 anyway
-                    if (kt == 0 || r < 8 || (r == 8 && !half)) P = (int)floorf(f[i < 25 ? i : 24] * F16);
+                    if (kt == 0 || r < 8 || (r == 8 && !half)) P = (int)(f[i < 25 ? i : 24] * F16);   // >= 0: truncation is the floor
                     word |= (unsigned)((P - 64) & 0xff) << (8 * e);
                 }
                 pf[kt][w] = (int)word;
