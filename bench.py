@@ -191,7 +191,7 @@ def main():
         g_n = sum(per.get(n, [0, 0])[1] for n in gemm_names) / max(args.profile_steps, 1)
         achieved = (lin_ops * args.batch / (g_ms * 1e-3) / 1e12) if g_ms > 0 else None
         roofline = {
-            "kernel": "gemm_nt_kernel<int8> (QuantLinear GEMMs: patch-embed, qkv, proj, fc1, fc2, head)",
+            "kernel": "gemm_glds_kernel (QuantLinear GEMMs with fused requant epilogues: patch-embed, qkv, proj, fc1, fc2) + head",
             "bound": "mfma", "achieved": None if achieved is None else round(achieved, 1),
             "peak": INT8_PEAK_TOPS, "unit": "TOP/s",
             "frac": None if achieved is None else round(achieved / INT8_PEAK_TOPS, 4),
@@ -199,6 +199,7 @@ def main():
             "launches_per_step": g_n, "ms_per_step_in_kernel": round(g_ms, 4),
             "avg_launch_ms": round(g_ms / g_n, 5) if g_n else None,
             "algorithmic_ops_per_step": lin_ops * args.batch,
+            "mfma_ubench_ceiling_tops_random_operands": 3400.0,   # tools/ubench/mfma_peak.hip, profiles/README.md
         }
         breakdown = {n: {"ms_per_step": round(v[0] / args.profile_steps, 4), "launches": v[1] // args.profile_steps}
                      for n, v in sorted(per.items(), key=lambda kv: -kv[1][0])}
