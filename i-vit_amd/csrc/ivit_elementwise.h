@@ -57,6 +57,45 @@ __global__ __launch_bounds__(256) void requant_kernel(const ZT *__restrict__ z, 
     }
 }
 
+// the same for C % 8 == 0: one thread per 8 consecutive channels (one 32-bit index split per thread
+// instead of a 64-bit modulo per element)
+template <typename ZT, int BITS>
+__global__ __launch_bounds__(256) void requant_vec8_kernel(const ZT *__restrict__ z, const ivit_dyadic *__restrict__ dy,
+                                                           int nch, const int32_t *__restrict__ z_id,
+                                                           const ivit_dyadic *__restrict__ dy_id, void *__restrict__ out,
+                                                           long long total8, int C8) {
+    double cid = 0.0;
+    if (z_id) cid = dy_id[0].m * dy_id[0].r;
+    const double c0 = dy[0].m * dy[0].r;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total8; i += (long long)gridDim.x * 256) {
+        const int c8 = (int)(i % C8);
+        const ZT *zp = z + i * 8;
+        int ob[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            double c = c0;
+            if (nch != 1) { const ivit_dyadic d = dy[c8 * 8 + e]; c = d.m * d.r; }
+            double o = __builtin_rint((double)zp[e] * c);
+            if (z_id) o = __builtin_rint((double)z_id[i * 8 + e] * cid) + o;
+            ob[e] = clamp_b<BITS>(o);
+        }
+        if (BITS == 8) {
+            unsigned lo = 0, hi = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { lo |= ((unsigned)ob[e] & 0xffu) << (8 * e); hi |= ((unsigned)ob[4 + e] & 0xffu) << (8 * e); }
+            *reinterpret_cast<v2i *>(reinterpret_cast<int8_t *>(out) + i * 8) = v2i{(int)lo, (int)hi};
+        } else if (BITS == 16) {
+            v8s o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (short)ob[e];
+            *reinterpret_cast<v8s *>(reinterpret_cast<int16_t *>(out) + i * 8) = o;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) reinterpret_cast<int32_t *>(out)[i * 8 + e] = ob[e];
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // a7 (+a3): I-LayerNorm (quant_modules.py:353-386).  32 lanes per row (two rows per
 // wavefront, 8 rows per 256-thread block); the row's fl(fl(Q*s)/s) values are staged
@@ -365,23 +404,27 @@ __global__ __launch_bounds__(256) void shiftgelu_kernel(const int8_t *__restrict
 
 // ---------------------------------------------------------------------------
 // a8: patch gather (layers_quant.py:184-196): NCHW int8 -> [B*gh*gw, Cin*P*P],
-// element order (c, py, px) = conv weight order.  One thread per 4 output bytes.
+// element order (c, py, px) = conv weight order.  One block per (image, patch row): the Cin*P image
+// rows of the strip are read as whole contiguous rows into LDS and leave as gw contiguous patch rows —
+// both HBM sides fully coalesced (the one-pass form fetched 5x the algorithmic bytes).
 __global__ __launch_bounds__(256) void im2col_patch_kernel(const int8_t *__restrict__ img, int B, int Cin, int H,
                                                            int W, int P, int8_t *__restrict__ rows) {
+    extern __shared__ __attribute__((aligned(16))) char dsmem[];
     const int gh = H / P, gw = W / P, K = Cin * P * P;
-    const long long total4 = (long long)B * gh * gw * K / 4;
-    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long stride = (long long)gridDim.x * 256;
-    for (; i < total4; i += stride) {
-        long long e = i * 4;
-        int kk = (int)(e % K);
-        long long prow = e / K;
-        int gx = (int)(prow % gw);
-        int gy = (int)((prow / gw) % gh);
-        int b = (int)(prow / ((long long)gw * gh));
-        int px = kk % P, py = (kk / P) % P, c = kk / (P * P);
-        const int8_t *src = img + (((long long)b * Cin + c) * H + gy * P + py) * W + gx * P + px;
-        *reinterpret_cast<int *>(rows + e) = *reinterpret_cast<const int *>(src);
+    const int b = blockIdx.x / gh, gy = blockIdx.x - b * gh;
+    const int S = Cin * P * W;                       // strip bytes, layout [c][py][x]
+    const int tid = threadIdx.x;
+    for (int idx = tid * 4; idx < S; idx += 256 * 4) {
+        const int x = idx % W, r = idx / W, py = r % P, c = r / P;
+        *reinterpret_cast<int *>(dsmem + idx) =
+            *reinterpret_cast<const int *>(img + (((long long)b * Cin + c) * H + gy * P + py) * W + x);
+    }
+    __syncthreads();
+    int8_t *dst = rows + ((long long)b * gh + gy) * gw * K;
+    for (int o = tid * 4; o < S; o += 256 * 4) {
+        const int gx = o / K, kk = o - gx * K;
+        const int px = kk % P, r = kk / P;           // r = c*P + py
+        *reinterpret_cast<int *>(dst + o) = *reinterpret_cast<const int *>(dsmem + r * W + gx * P + px);
     }
 }
 
@@ -391,16 +434,31 @@ __global__ __launch_bounds__(256) void embed_finish_kernel(const int16_t *__rest
                                                            const int16_t *__restrict__ pos, ivit_dyadic dx,
                                                            ivit_dyadic dp, int16_t *__restrict__ x16, int B, int T,
                                                            int D) {
-    const long long total = (long long)B * T * D;
-    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long stride = (long long)gridDim.x * 256;
-    for (; i < total; i += stride) {
-        int d = (int)(i % D);
-        int t = (int)((i / D) % T);
-        int b = (int)(i / ((long long)D * T));
-        int z = t == 0 ? z_cls[d] : (int)patch16[((long long)b * (T - 1) + (t - 1)) * D + d];
-        double o = rq_f64((double)pos[(long long)t * D + d], dp.m, dp.r) + rq_f64((double)z, dx.m, dx.r);
-        x16[i] = (int16_t)clamp_b<16>(o);
+    // one thread per 8 channels (16-byte loads/stores); all index arithmetic in 32 bits, once per thread
+    const int D8 = D >> 3;
+    const long long total = (long long)B * T * D8;
+    const double cx = dx.m * dx.r, cp = dp.m * dp.r;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int row = (int)(i / D8), c8 = (int)(i - (long long)row * D8);
+        const int b = row / T, t = row - b * T;
+        const v8s pv = *reinterpret_cast<const v8s *>(pos + (long long)t * D + c8 * 8);
+        int z[8];
+        if (t == 0) {
+            const v4i a0 = *reinterpret_cast<const v4i *>(z_cls + c8 * 8), a1 = *reinterpret_cast<const v4i *>(z_cls + c8 * 8 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { z[e] = a0[e]; z[4 + e] = a1[e]; }
+        } else {
+            const v8s xv = *reinterpret_cast<const v8s *>(patch16 + ((long long)b * (T - 1) + (t - 1)) * D + c8 * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) z[e] = xv[e];
+        }
+        v8s o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const double v = __builtin_rint((double)pv[e] * cp) + __builtin_rint((double)z[e] * cx);
+            o[e] = (short)clamp_b<16>(v);
+        }
+        *reinterpret_cast<v8s *>(x16 + i * 8) = o;
     }
 }
 

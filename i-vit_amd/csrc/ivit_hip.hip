@@ -289,6 +289,14 @@ template <typename ZT>
 static int requant_any(ivit_handle h, const ZT *z, const ivit_dyadic *dy, int nch, const int32_t *z_id,
                        const ivit_dyadic *dy_id, int bits, void *out, int64_t rows, int C) {
     const long long total = (long long)rows * C;
+    if ((C % 8) == 0 && nch == 1) {   // per-channel tables keep the element-per-lane form (coalesced constant loads)
+        const int g8 = grid_for(h, total / 8, 256 * 2);
+        if (bits == 8) requant_vec8_kernel<ZT, 8><<<g8, 256, 0, h->stream>>>(z, dy, nch, z_id, dy_id, out, total / 8, C / 8);
+        else if (bits == 16) requant_vec8_kernel<ZT, 16><<<g8, 256, 0, h->stream>>>(z, dy, nch, z_id, dy_id, out, total / 8, C / 8);
+        else requant_vec8_kernel<ZT, 32><<<g8, 256, 0, h->stream>>>(z, dy, nch, z_id, dy_id, out, total / 8, C / 8);
+        LAUNCH_CHECK(h);
+        return IVIT_OK;
+    }
     const int g = grid_for(h, total, 256 * 4);
     if (bits == 8) requant_kernel<ZT, 8><<<g, 256, 0, h->stream>>>(z, dy, nch, z_id, dy_id, out, total, C);
     else if (bits == 16) requant_kernel<ZT, 16><<<g, 256, 0, h->stream>>>(z, dy, nch, z_id, dy_id, out, total, C);
@@ -529,8 +537,9 @@ int ivit_im2col_patch(ivit_handle h, const int8_t *img, int B, int Cin, int H, i
     CHECK_H(h);
     REQUIRE(h, img && rows && B > 0 && Cin > 0 && P > 0, "bad arguments");
     REQUIRE(h, (H % P) == 0 && (W % P) == 0 && (P % 4) == 0 && (W % 4) == 0, "H,W multiples of P; P,W multiples of 4");
-    const long long total4 = (long long)B * H * W * Cin / 4;
-    im2col_patch_kernel<<<grid_for(h, total4, 256), 256, 0, h->stream>>>(img, B, Cin, H, W, P, rows);
+    const size_t lds = (size_t)Cin * P * W;
+    REQUIRE(h, lds <= 64 * 1024, "patch strip too large for LDS staging");
+    im2col_patch_kernel<<<(unsigned)(B * (H / P)), 256, lds, h->stream>>>(img, B, Cin, H, W, P, rows);
     LAUNCH_CHECK(h);
     return IVIT_OK;
 }
@@ -538,8 +547,8 @@ int ivit_im2col_patch(ivit_handle h, const int8_t *img, int B, int Cin, int H, i
 int ivit_embed_finish(ivit_handle h, const int16_t *patch16, const int32_t *z_cls, const int16_t *pos,
                       ivit_dyadic dy_x, ivit_dyadic dy_pos, int16_t *x16, int B, int T, int D) {
     CHECK_H(h);
-    REQUIRE(h, patch16 && z_cls && pos && x16 && B > 0 && T > 1 && D > 0, "bad arguments");
-    embed_finish_kernel<<<grid_for(h, (long long)B * T * D, 256), 256, 0, h->stream>>>(patch16, z_cls, pos, dy_x, dy_pos, x16, B, T, D);
+    REQUIRE(h, patch16 && z_cls && pos && x16 && B > 0 && T > 1 && D > 0 && (D % 8) == 0, "bad arguments (D must be a multiple of 8)");
+    embed_finish_kernel<<<grid_for(h, (long long)B * T * D / 8, 256), 256, 0, h->stream>>>(patch16, z_cls, pos, dy_x, dy_pos, x16, B, T, D);
     LAUNCH_CHECK(h);
     return IVIT_OK;
 }
