@@ -571,3 +571,41 @@ def test_imported_reference_state_dict_runs_to_golden_logits():
         acc, _ = m(dev(imgs))
     assert np.array_equal(acc.cpu().numpy(), g["logits_int"])
     assert np.array_equal(m.compile().forward(dev(imgs)).cpu().numpy(), g["logits_int"])
+
+
+def test_full_size_batch_properties_deit_small_b256():
+    """BASELINE config 2 at full size (DeiT-S, 256 images): the oracle is too slow here, so parity rides on
+    size-independent properties — images are independent, so (i) the golden 4-image prefix is reproduced
+    inside the big batch, (ii) permuting the batch permutes the logits, (iii) duplicated images give
+    duplicated logits, (iv) slices / hipGraph give the same integers as one stream."""
+    g = load_golden("deit_small_b4.npz")
+    cfg, w, eng = _engine_for(g)
+    B = 256
+    imgs = np.concatenate([iv.make_images_int8(cfg, 4, int(g["images_seed"])), iv.make_images_int8(cfg, B - 4, seed=11)])
+    imgs[200:204] = imgs[0:4]                                  # duplicates
+    d = dev(imgs)
+    ref = eng.forward(d).cpu().numpy()
+    assert np.array_equal(ref[:4], g["logits_int"])
+    assert np.array_equal(ref[200:204], ref[0:4])
+    perm = np.random.default_rng(5).permutation(B)
+    out_p = eng.forward(dev(imgs[perm])).cpu().numpy()
+    assert np.array_equal(out_p, ref[perm])
+    assert np.array_equal(eng.forward(d, nslices=4).cpu().numpy(), ref)
+    rep = eng.capture(d, 4)
+    out = rep()
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), ref)
+
+
+def test_full_size_batch_properties_swin_tiny_b64():
+    """Swin-T at a large batch: golden image inside the batch, permutation equivariance."""
+    from ivit_amd.swin_engine import SwinEngine
+    g = load_golden("swin_tiny_b1.npz")
+    cfg = iv.SWIN_CONFIGS[str(g["cfg_name"])]
+    eng = SwinEngine(cfg, iv.make_swin_weights(cfg, int(g["seed"])), golden_scales(g))
+    B = 64
+    imgs = np.concatenate([iv.make_images_int8(cfg, 1, int(g["images_seed"])), iv.make_images_int8(cfg, B - 1, seed=12)])
+    ref = eng.forward(dev(imgs)).cpu().numpy().copy()
+    assert np.array_equal(ref[:1], g["logits_int"])
+    perm = np.random.default_rng(6).permutation(B)
+    assert np.array_equal(eng.forward(dev(imgs[perm])).cpu().numpy(), ref[perm])
