@@ -46,9 +46,11 @@ __device__ __forceinline__ int rq_lean(int z, double c, int lo, int hi) {
 }
 __device__ __forceinline__ int rq_lean_wide(int z, double c) { return (int)__builtin_rint((double)z * c); }
 
+// kchunks: valid 16-byte chunks of this K step (4, or 2 for the 32-wide tail step when K % 64 == 32): lanes whose
+// chunk lies beyond K are masked off — their LDS slots keep stale bytes that the tail step never feeds to an MFMA
 template <int BM>
 __device__ __forceinline__ void g2_issue(const int8_t *A, const int8_t *B, int lda, int ldb, int M, int N,
-                                         int row0, int col0, int k0, char *stage, int tid) {
+                                         int row0, int col0, int k0, char *stage, int tid, int kchunks = 4) {
     using Cf = G2Cfg<BM>;
     const int wave = tid >> 6;
 #pragma unroll
@@ -58,8 +60,9 @@ __device__ __forceinline__ void g2_issue(const int8_t *A, const int8_t *B, int l
         int grow = min(row0 + row, M - 1);
         const int8_t *src = A + (long long)grow * lda + k0 + c * 16;
         unsigned loff = __builtin_amdgcn_readfirstlane((unsigned)(i * (Cf::THREADS * 16) + wave * 1024));
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                         (__attribute__((address_space(3))) void *)(stage + loff), 16, 0, 0);
+        if (c < kchunks)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(stage + loff), 16, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < Cf::B_PER_THREAD; ++i) {
@@ -68,8 +71,9 @@ __device__ __forceinline__ void g2_issue(const int8_t *A, const int8_t *B, int l
         int grow = min(col0 + row, N - 1);
         const int8_t *src = B + (long long)grow * ldb + k0 + c * 16;
         unsigned loff = __builtin_amdgcn_readfirstlane((unsigned)(BM * 64 + i * (Cf::THREADS * 16) + wave * 1024));
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                         (__attribute__((address_space(3))) void *)(stage + loff), 16, 0, 0);
+        if (c < kchunks)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(stage + loff), 16, 0, 0);
     }
 }
 
@@ -95,9 +99,11 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 4 : (G2_NSTAGE128 == 2 ? 4 : 3)
     const int8_t *B = p.B;
 
     const int Kdim = p.K;
-    const int nk = Kdim / G2_BK;
-    g2_issue<BM>(A, B, p.lda, p.ldb, p.M, p.N, row0, col0, 0, smem, tid);
-    if (NS == 3 && nk > 1) g2_issue<BM>(A, B, p.lda, p.ldb, p.M, p.N, row0, col0, G2_BK, smem + G2_STAGE, tid);
+    const int nk = (Kdim + G2_BK - 1) / G2_BK;
+    const bool ktail = (Kdim % G2_BK) != 0;            // K % 64 == 32: the last step carries 32 columns
+    auto kch = [&](int kt) { return (ktail && kt == nk - 1) ? 2 : 4; };
+    g2_issue<BM>(A, B, p.lda, p.ldb, p.M, p.N, row0, col0, 0, smem, tid, kch(0));
+    if (NS == 3 && nk > 1) g2_issue<BM>(A, B, p.lda, p.ldb, p.M, p.N, row0, col0, G2_BK, smem + G2_STAGE, tid, kch(1));
 
     // per-channel constants of this column block -> LDS (read back in the epilogue; the
     // K-loop barriers order the write): c[n] = m*2^-e (exact in fp64), bias[n]
@@ -140,11 +146,12 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 4 : (G2_NSTAGE128 == 2 ? 4 : 3)
         asm volatile("" ::: "memory");
         if (kt + NS - 1 < nk)
             g2_issue<BM>(A, B, p.lda, p.ldb, p.M, p.N, row0, col0, (kt + NS - 1) * G2_BK,
-                     smem + ((kt + NS - 1) % NS) * G2_STAGE, tid);
+                     smem + ((kt + NS - 1) % NS) * G2_STAGE, tid, kch(kt + NS - 1));
         const char *sA = smem + (kt % NS) * G2_STAGE;
         const char *sB = sA + BM * 64;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
+            if (kk == 1 && ktail && kt == nk - 1) break;   // 32-wide tail step
             const int chunk = kk * 2 + half;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {

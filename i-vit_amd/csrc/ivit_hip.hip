@@ -122,7 +122,7 @@ static int launch_gemm2(ivit_handle h, GemmArgs &a) {
     }
     return IVIT_OK;
 }
-static inline bool use_gemm2(const GemmArgs &a) { return (a.K % G2_BK) == 0 && (a.lda % 16) == 0 && (a.ldb % 16) == 0; }
+static inline bool use_gemm2(const GemmArgs &a) { return (a.K % 32) == 0 && a.K >= 64 && (a.lda % 16) == 0 && (a.ldb % 16) == 0; }
 
 static GemmArgs linear_args(const int8_t *x, const int8_t *w, const int32_t *bias, int M, int N, int K) {
     GemmArgs a;

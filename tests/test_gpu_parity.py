@@ -180,10 +180,12 @@ def test_linear_i8_vs_numpy(H, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 128, 64), (788, 384, 384), (300, 1152, 192), (197, 1000, 384),
-                                   (50, 10, 64), (513, 136, 1536), (394, 384, 48)])
+                                   (50, 10, 64), (513, 136, 1536), (394, 384, 48), (300, 288, 96), (257, 96, 96),
+                                   (130, 384, 160), (640, 96, 352)])
 def test_linear_requant_epilogues_vs_oracle(H, M, N, K):
     """a1+a3 fused epilogues (8-bit, 16-bit, 16-bit + residual) == oracle linear + requant.
-    K % 64 == 0 shapes take the global_load_lds kernel, the last one the generic kernel."""
+    K % 32 == 0 (K >= 64) shapes take the global_load_lds kernel — K % 64 == 32 through its masked 32-wide
+    tail step (Swin stage 0, K = 96) — and K = 48 the generic kernel."""
     from oracle import oracle as orc
     rng = np.random.default_rng(M + N + K)
     x = rng.integers(-128, 128, (M, K), dtype=np.int8)
