@@ -156,9 +156,9 @@ class SwinEngine:
             self.t[name] = torch.tensor([[d.m, d.r]], dtype=torch.float64, device=self.device)
         return _P(self.t[name].data_ptr())
 
-    def workspace(self, B):
-        if B in self._ws:
-            return self._ws[B]
+    def workspace(self, B, key=None):
+        if (B, key) in self._ws:
+            return self._ws[(B, key)]
         cfg, dev = self.cfg, self.device
         L0, E = cfg.grid * cfg.grid, cfg.embed_dim
         e = lambda n, dt: torch.empty(n, dtype=dt, device=dev)
@@ -174,16 +174,38 @@ class SwinEngine:
             pool=e(B * E * 2 ** (cfg.num_layers - 1), torch.int8),
             logits=torch.empty(B, cfg.num_classes, dtype=torch.int32, device=dev),
         )
-        self._ws[B] = ws
+        self._ws[(B, key)] = ws
         return ws
 
-    def forward(self, images):
-        """images int8 [B, C, H, W] (scale qact_input) -> int32 logits [B, num_classes]."""
+    def forward(self, images, nslices=1):
+        """images int8 [B, C, H, W] (scale qact_input) -> int32 logits [B, num_classes].
+        nslices > 1: independent batch slices on separate HIP streams (VALU-bound attention / LayerNorm of
+        one slice share the chip with the GEMMs of another); same integers."""
+        if nslices > 1 and images.shape[0] >= nslices:
+            return self._forward_sliced(images, nslices)
+        return self._forward_one(images, None)
+
+    def _forward_sliced(self, images, nslices):
+        B = images.shape[0]
+        if not hasattr(self, "_streams") or len(self._streams) != nslices:
+            self._streams = [torch.cuda.Stream(self.device) for _ in range(nslices)]
+        cur = torch.cuda.current_stream(self.device)
+        bounds = [(B * i) // nslices for i in range(nslices + 1)]
+        outs = []
+        for i, st in enumerate(self._streams):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                outs.append(self._forward_one(images[bounds[i]:bounds[i + 1]], ("slice", i)))
+        for st in self._streams:
+            cur.wait_stream(st)
+        return torch.cat(outs, 0)
+
+    def _forward_one(self, images, ws_key):
         cfg, call, f, dy = self.cfg, self.h.call, self.f, self.dy
         assert images.dtype == torch.int8 and images.is_contiguous() and images.device == self.device
         self.h.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
         B = images.shape[0]
-        ws = self.workspace(B)
+        ws = self.workspace(B, ws_key)
         P = lambda t: _P(t.data_ptr())
         E, res = cfg.embed_dim, cfg.grid
         L = res * res
@@ -236,14 +258,14 @@ class SwinEngine:
         call("ivit_linear_i8", P(ws["pool"]), self.ptr("head.w"), self.ptr("head.b"), P(ws["logits"]), B, cfg.num_classes, C)
         return ws["logits"]
 
-    def capture(self, images):
+    def capture(self, images, nslices=1):
         """hipGraph of one forward on fixed buffers (every C-ABI call is capturable: nothing allocates or
         synchronises).  Returns a callable that replays it and returns the logits tensor."""
-        self.forward(images)                    # allocates the workspace outside the capture
+        self.forward(images, nslices)           # allocates the workspaces outside the capture
         torch.cuda.synchronize(self.device)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            out = self.forward(images)
+            out = self.forward(images, nslices)
 
         def replay():
             g.replay()

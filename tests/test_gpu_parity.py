@@ -611,3 +611,11 @@ def test_full_size_batch_properties_swin_tiny_b64():
     assert np.array_equal(ref[:1], g["logits_int"])
     perm = np.random.default_rng(6).permutation(B)
     assert np.array_equal(eng.forward(dev(imgs[perm])).cpu().numpy(), ref[perm])
+    # batch slices on separate streams, and the hipGraph of that
+    d = dev(imgs)
+    assert np.array_equal(eng.forward(d, nslices=3).cpu().numpy(), ref)
+    rep = eng.capture(d, 4)
+    for _ in range(3):
+        out = rep()
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), ref)

@@ -19,7 +19,8 @@ for batch in [int(x) for x in os.environ.get("SW_BATCH", "1,64,256").split(",")]
     n = 10 if batch > 1 else 50
     for _ in range(n): eng.forward(imgs)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t) / n
-    rep = eng.capture(imgs)
+    NS = int(os.environ.get("SW_SLICES", "4")) if batch >= 16 else 1
+    rep = eng.capture(imgs, NS)
     for _ in range(2): rep()
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(n): rep()
@@ -39,5 +40,5 @@ for batch in [int(x) for x in os.environ.get("SW_BATCH", "1,64,256").split(",")]
         d = per.setdefault(name, [0.0, 0]); d[0] += e0.elapsed_time(e1); d[1] += 1
     print(json.dumps({"config": "swin_tiny (SwinEngine, fused windowed attention)", "batch": batch, "ms": round(dt * 1e3, 3),
                       "images_per_s": round(batch / dt, 1), "bit_exact_vs_reference_golden": ok,
-                      "hipgraph_ms": round(dtg * 1e3, 3), "hipgraph_images_per_s": round(batch / dtg, 1), "hipgraph_bit_exact": okg,
+                      "hipgraph_slices": NS, "hipgraph_ms": round(dtg * 1e3, 3), "hipgraph_images_per_s": round(batch / dtg, 1), "hipgraph_bit_exact": okg,
                       "kernel_ms": {k: [round(v[0], 3), v[1]] for k, v in sorted(per.items(), key=lambda kv: -kv[1][0])}}), flush=True)
