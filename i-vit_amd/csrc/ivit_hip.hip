@@ -496,15 +496,15 @@ int ivit_layernorm_tokenorder_requant(ivit_handle h, const int16_t *x, int64_t r
                                       int tokens_per_image, int8_t *out8) {
     CHECK_H(h);
     REQUIRE(h, x && bias_int && sc && dy && out8 && rows > 0 && C > 0 && scale > 0.f && tokens_per_image > 0, "bad arguments");
-    const size_t lds = ((size_t)64 * (C + 1) + 3 * (size_t)C + 130) * sizeof(float) + (size_t)C * sizeof(double);
+    const size_t lds = ((size_t)LNT_ROWS * (C + 1) + 3 * (size_t)C + 2 * LNT_ROWS + 2) * sizeof(float) + (size_t)C * sizeof(double);
     REQUIRE(h, lds <= 160 * 1024, "C too large for LDS staging");
     if (C == 96) {          // Swin-T/S stage 0
-        layernorm_tokenorder_kernel<true, 96><<<(unsigned)((rows + 63) / 64), 256, lds, h->stream>>>(
+        layernorm_tokenorder_kernel<true, 96><<<(unsigned)((rows + LNT_ROWS - 1) / LNT_ROWS), 256, lds, h->stream>>>(
             x, rows, C, scale, bias_int, sc, dy, tokens_per_image, out8);
     } else {
         int st = set_dyn_lds(h, (const void *)layernorm_tokenorder_kernel<true, 0>, lds);
         if (st) return st;
-        layernorm_tokenorder_kernel<true, 0><<<(unsigned)((rows + 63) / 64), 256, lds, h->stream>>>(
+        layernorm_tokenorder_kernel<true, 0><<<(unsigned)((rows + LNT_ROWS - 1) / LNT_ROWS), 256, lds, h->stream>>>(
             x, rows, C, scale, bias_int, sc, dy, tokens_per_image, out8);
     }
     LAUNCH_CHECK(h);
@@ -515,11 +515,11 @@ int ivit_layernorm_tokenorder(ivit_handle h, const int16_t *x, int64_t rows, int
                               const float *bias_int, const float *sc, int tokens_per_image, float *z) {
     CHECK_H(h);
     REQUIRE(h, x && bias_int && sc && z && rows > 0 && C > 0 && scale > 0.f && tokens_per_image > 0, "bad arguments");
-    const size_t lds = ((size_t)64 * (C + 1) + 3 * (size_t)C + 130) * sizeof(float) + (size_t)C * sizeof(double);
+    const size_t lds = ((size_t)LNT_ROWS * (C + 1) + 3 * (size_t)C + 2 * LNT_ROWS + 2) * sizeof(float) + (size_t)C * sizeof(double);
     REQUIRE(h, lds <= 160 * 1024, "C too large for LDS staging");
     int st = set_dyn_lds(h, (const void *)layernorm_tokenorder_kernel<false, 0>, lds);
     if (st) return st;
-    layernorm_tokenorder_kernel<false, 0><<<(unsigned)((rows + 63) / 64), 256, lds, h->stream>>>(
+    layernorm_tokenorder_kernel<false, 0><<<(unsigned)((rows + LNT_ROWS - 1) / LNT_ROWS), 256, lds, h->stream>>>(
         x, rows, C, scale, bias_int, sc, nullptr, tokens_per_image, z);
     LAUNCH_CHECK(h);
     return IVIT_OK;

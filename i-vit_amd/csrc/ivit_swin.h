@@ -120,9 +120,10 @@ __device__ __forceinline__ float strided_order_sum(const float *x, int n, bool i
     return ps0;
 }
 
-// 64 tokens per 256-thread block: the loads (with fl(fl(Q*s)/s)) and the normalise / requant / store pass
+// LNT_ROWS tokens per 256-thread block: the loads (with fl(fl(Q*s)/s)) and the normalise / requant / store pass
 // are spread over all threads; only the two order-sensitive sums and the integer square root of a token run
-// on one thread (wave 0, one token per lane).  Per-channel divisors use the hoisted reciprocal (lean_div).
+// on one thread (the first LNT_ROWS threads, one token each).  Per-channel divisors use the hoisted reciprocal (lean_div).
+#define LNT_ROWS 32
 template <bool OUT8, int CC>   // CC: compile-time channel count (index arithmetic by constants), 0 = run-time
 __global__ __launch_bounds__(256) void layernorm_tokenorder_kernel(const int16_t *__restrict__ x, long long rows, int C_rt,
                                                                    float s, const float *__restrict__ bias_int,
@@ -132,12 +133,12 @@ __global__ __launch_bounds__(256) void layernorm_tokenorder_kernel(const int16_t
     const int C = CC ? CC : C_rt;
     extern __shared__ __attribute__((aligned(16))) char dsmem[];
     const int LD = C + 1;
-    float *tile = reinterpret_cast<float *>(dsmem);            // [64][C + 1]
-    float *cSc = tile + 64 * LD, *cY = cSc + C, *cB = cY + C;  // per-channel sc, refined 1/sc, bias_int
-    float *rMean = cB + C, *rF = rMean + 64;                   // per-token mean and factor
-    double *cC = reinterpret_cast<double *>(rF + 64 + ((64 * LD + 3 * C + 128) & 1));   // 8-byte aligned
+    float *tile = reinterpret_cast<float *>(dsmem);            // [LNT_ROWS][C + 1]
+    float *cSc = tile + LNT_ROWS * LD, *cY = cSc + C, *cB = cY + C;  // per-channel sc, refined 1/sc, bias_int
+    float *rMean = cB + C, *rF = rMean + LNT_ROWS;                   // per-token mean and factor
+    double *cC = reinterpret_cast<double *>(rF + LNT_ROWS + ((LNT_ROWS * LD + 3 * C + 2 * LNT_ROWS) & 1));   // 8-byte aligned
     const int tid = threadIdx.x;
-    const long long row0 = (long long)blockIdx.x * 64;
+    const long long row0 = (long long)blockIdx.x * LNT_ROWS;
     const RcpC sr = rcp_prepare(s);
     for (int c = tid; c < C; c += 256) {
         const float scv = sc[c];
@@ -146,14 +147,14 @@ __global__ __launch_bounds__(256) void layernorm_tokenorder_kernel(const int16_t
         cB[c] = bias_int[c];
         if (OUT8) cC[c] = dy[c].m * dy[c].r;
     }
-    const int total = 64 * C;
+    const int total = LNT_ROWS * C;
     for (int e = tid; e < total; e += 256) {
         const int r = e / C, c = e - r * C;
         const long long gr = row0 + r;
         tile[r * LD + c] = gr < rows ? requotient_c((float)x[gr * C + c], sr) : 0.f;
     }
     __syncthreads();
-    if (tid < 64) {
+    if (tid < LNT_ROWS) {
         const long long row = row0 + tid;
         const float *xr = tile + tid * LD;
         float mean = 0.f, F = 0.f;
