@@ -274,6 +274,14 @@ class SwinTransformer(nn.Module):
         x, s = self.head(x, s)
         return x, s
 
+    def int8_logits(self, acc, scale):
+        """The 8-bit output requant the reference defines but never runs (`act_out`, vit_quant.py:240 and the
+        commented-out call at :281; same in swin_quant.py): QuantAct(8) on the head's int32 accumulators with
+        their per-class scale.  While `act_out.running_stat` it calibrates its range from these logits like
+        any other site; once frozen it is one per-channel dyadic requant.  Not pinned by the reference (it has
+        no scale for this site) — a build-side extra.  -> (int8 [B, classes], scale)"""
+        return self.act_out(acc, scale)
+
 
 def _swin(pretrained=False, **kw):
     if pretrained:

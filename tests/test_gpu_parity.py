@@ -619,3 +619,30 @@ def test_full_size_batch_properties_swin_tiny_b64():
         out = rep()
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy(), ref)
+
+
+def test_act_out_int8_logits_extension():
+    """N4: the reference's never-called `act_out` QuantAct as a defined int8-logits epilogue: calibrates from
+    the logits, then equals the oracle's per-class dyadic requant of the head accumulators."""
+    from oracle import oracle as orc
+    g = load_golden("micro_vit2h_b3.npz")
+    cfg = iv.CONFIGS[str(g["cfg_name"])]
+    m = iv.VisionTransformer(img_size=cfg.img_size, patch_size=cfg.patch_size, num_classes=cfg.num_classes,
+                             embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads, mlp_ratio=4)
+    m.load_float_weights(iv.make_vit_weights(cfg, int(g["seed"]))).load_act_scales(golden_scales(g))
+    iv.freeze_model(m)
+    imgs = iv.make_images_int8(cfg, int(g["batch"]), int(g["images_seed"]))
+    with torch.no_grad():
+        acc, scale = m(dev(imgs))
+        m.act_out.unfix()                       # calibrate this one site from the logits it sees
+        q8, s8 = m.int8_logits(acc, scale)
+        m.act_out.fix()
+        q8b, s8b = m.int8_logits(acc, scale)
+    assert np.array_equal(acc.cpu().numpy(), g["logits_int"])
+    X = acc.cpu().numpy().astype(np.float32) * g["logits_scale"].astype(np.float32)
+    s_ref = iv.freeze.symmetric_scale(X.min(), X.max(), 8)
+    assert np.float32(s8.reshape(-1)[0].item()) == np.float32(s_ref)
+    ref = orc.requant(g["logits_int"].astype(np.int32), orc.dyadic(g["logits_scale"], np.float32(s_ref)), 8)
+    assert np.array_equal(q8.cpu().numpy().astype(np.int32), ref)
+    assert np.array_equal(q8b.cpu().numpy(), q8.cpu().numpy()) and q8.dtype == torch.int8
+    assert np.abs(q8.cpu().numpy().astype(np.int32)).max() == 127       # the calibrated range is used in full
