@@ -70,6 +70,49 @@ class VitParams(ctypes.Structure):
     ]
 
 
+class LnParams(ctypes.Structure):
+    """struct ivit_ln_params"""
+    _fields_ = [("bias_int", ctypes.c_void_p), ("sc", ctypes.c_void_p), ("dy", ctypes.c_void_p)]
+
+
+class LinParams(ctypes.Structure):
+    """struct ivit_lin_params"""
+    _fields_ = [("w", ctypes.c_void_p), ("b", ctypes.c_void_p), ("dy", ctypes.c_void_p)]
+
+
+class SwinConfigC(ctypes.Structure):
+    """struct ivit_swin_config"""
+    _fields_ = [(n, ctypes.c_int) for n in ("img_size", "patch_size", "in_chans", "embed_dim", "num_layers", "window_size",
+                                             "mlp_ratio", "num_classes")] + [("depths", ctypes.c_int * 4), ("num_heads", ctypes.c_int * 4)]
+
+
+class SwinBlock(ctypes.Structure):
+    """struct ivit_swin_block"""
+    _fields_ = [
+        ("s_in", ctypes.c_float), ("n1", LnParams), ("qkv", LinParams),
+        ("dy_qk", Dyadic), ("dy_a", Dyadic), ("relb", ctypes.c_void_p),
+        ("s_softmax", ctypes.c_float), ("dy_pv", Dyadic), ("proj", LinParams),
+        ("res1_main", Dyadic), ("res1_res", Dyadic),
+        ("s_mid", ctypes.c_float), ("n2", LnParams), ("fc1", LinParams), ("s_gelu", ctypes.c_float), ("dy_gelu", Dyadic),
+        ("fc2", LinParams), ("res2_main", Dyadic), ("res2_res", Dyadic),
+    ]
+
+
+class SwinMerge(ctypes.Structure):
+    """struct ivit_swin_merge"""
+    _fields_ = [("s_in", ctypes.c_float), ("n", LnParams), ("red", LinParams)]
+
+
+class SwinParams(ctypes.Structure):
+    """struct ivit_swin_params"""
+    _fields_ = [
+        ("pe", LinParams), ("s_bn", ctypes.c_float), ("pn", LnParams), ("dy_qact1", ctypes.c_void_p),
+        ("blocks_host", ctypes.POINTER(SwinBlock)), ("merges_host", ctypes.POINTER(SwinMerge)),
+        ("s_norm_in", ctypes.c_float), ("n", LnParams), ("dy_pool", Dyadic),
+        ("head_w", ctypes.c_void_p), ("head_b", ctypes.c_void_p),
+    ]
+
+
 _P = ctypes.c_void_p
 _I = ctypes.c_int
 _L = ctypes.c_int64
@@ -86,6 +129,11 @@ SIGNATURES = {
     "ivit_window_attention_fused": [_P, _P, Dyadic, Dyadic, _P, _F, Dyadic, _P, _I, _I, _I, _I, _I, _I],
     "ivit_patch_merge_gather": [_P, _P, _I, _I, _I, _I, _P],
     "ivit_widen_i8_i16": [_P, _P, _P, _L],
+    "ivit_swin_create": [_P, ctypes.POINTER(SwinConfigC), ctypes.POINTER(SwinParams), _I, ctypes.POINTER(_P)],
+    "ivit_swin_destroy": [_P],
+    "ivit_swin_workspace_bytes": [_P, _I, _I, ctypes.POINTER(ctypes.c_size_t)],
+    "ivit_swin_forward": [_P, _P, _I, _I, _P, ctypes.c_size_t, _P],
+    "ivit_swin_graph_create": [_P, _P, _I, _I, _P, ctypes.c_size_t, _P, ctypes.POINTER(_P)],
     "ivit_vit_create": [_P, ctypes.POINTER(VitConfig), ctypes.POINTER(VitParams), _I, ctypes.POINTER(_P)],
     "ivit_vit_destroy": [_P],
     "ivit_vit_workspace_bytes": [_P, _I, _I, ctypes.POINTER(ctypes.c_size_t)],

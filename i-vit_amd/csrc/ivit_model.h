@@ -21,7 +21,7 @@ struct ivit_vit_s {
 };
 
 struct ivit_graph_s {
-    ivit_vit m;
+    ivit_handle h;
     hipGraph_t graph;
     hipGraphExec_t exec;
 };
@@ -250,15 +250,15 @@ int ivit_vit_graph_create(ivit_vit m, const int8_t *images, int batch, int nslic
     e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     if (e != hipSuccess) { hipGraphDestroy(graph); snprintf(h->err, sizeof(h->err), "instantiate: %s", hipGetErrorString(e)); return IVIT_ERR_HIP; }
     ivit_graph_s *g = new ivit_graph_s();
-    g->m = m; g->graph = graph; g->exec = exec;
+    g->h = h; g->graph = graph; g->exec = exec;
     *out = g;
     return IVIT_OK;
 }
 
 int ivit_graph_launch(ivit_graph g) {
     if (!g) return IVIT_ERR_INVALID;
-    hipError_t e = hipGraphLaunch(g->exec, g->m->h->stream);
-    if (e != hipSuccess) { snprintf(g->m->h->err, sizeof(g->m->h->err), "graph launch: %s", hipGetErrorString(e)); return IVIT_ERR_HIP; }
+    hipError_t e = hipGraphLaunch(g->exec, g->h->stream);
+    if (e != hipSuccess) { snprintf(g->h->err, sizeof(g->h->err), "graph launch: %s", hipGetErrorString(e)); return IVIT_ERR_HIP; }
     return IVIT_OK;
 }
 
@@ -267,6 +267,239 @@ int ivit_graph_destroy(ivit_graph g) {
     hipGraphExecDestroy(g->exec);
     hipGraphDestroy(g->graph);
     delete g;
+    return IVIT_OK;
+}
+
+}  // extern "C"
+
+// =====================================================================================================
+// Swin runner
+struct ivit_swin_s {
+    ivit_handle h;
+    ivit_swin_config cfg;
+    ivit_swin_params prm;
+    std::vector<ivit_swin_block> blocks;
+    std::vector<ivit_swin_merge> merges;
+    int grid, nblocks;
+    int8_t *gelu_tab;                 // [nblocks][65536]
+    int max_slices;
+    std::vector<ivit_handle> slice_h;
+    std::vector<hipStream_t> streams;
+    std::vector<hipEvent_t> done;
+    hipEvent_t fork;
+};
+
+namespace {
+
+struct SwinLayout { size_t patches, a8, xa, xb, xc, zf, qkv, ctx, h8, g8, pool, total; };
+
+SwinLayout swin_layout(const ivit_swin_s *m, int B) {
+    const ivit_swin_config &c = m->cfg;
+    const size_t M0 = (size_t)B * m->grid * m->grid, E = c.embed_dim;
+    SwinLayout L;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o = al256(o + bytes + 64); return at; };
+    L.patches = take(M0 * c.in_chans * c.patch_size * c.patch_size);
+    L.a8 = take(M0 * E);
+    L.xa = take(M0 * E * 2);
+    L.xb = take(M0 * E * 2);
+    L.xc = take(M0 * E * 2);
+    L.zf = take(M0 * E * 4);
+    L.qkv = take(M0 * 3 * E);
+    L.ctx = take(M0 * E);
+    L.h8 = take(M0 * c.mlp_ratio * E);
+    L.g8 = take(M0 * c.mlp_ratio * E);
+    L.pool = take((size_t)B * (E << (c.num_layers - 1)));
+    L.total = o;
+    return L;
+}
+
+int swin_ln(const ivit_swin_s *m, ivit_handle h, const int16_t *x, long long M, int C, float s_in, const ivit_ln_params &n,
+            int L, bool token_order, int8_t *out8) {
+    if (token_order) return ivit_layernorm_tokenorder_requant(h, x, M, C, s_in, n.bias_int, n.sc, n.dy, L, out8);
+    return ivit_layernorm_requant(h, x, M, C, C, s_in, n.bias_int, n.sc, n.dy, out8);
+}
+
+int swin_run_slice(const ivit_swin_s *m, ivit_handle h, const int8_t *images, int B, char *ws, int32_t *logits) {
+    const ivit_swin_config &c = m->cfg;
+    const ivit_swin_params &P = m->prm;
+    const SwinLayout Lw = swin_layout(m, B);
+    int8_t *patches = (int8_t *)(ws + Lw.patches), *a8 = (int8_t *)(ws + Lw.a8), *qkv = (int8_t *)(ws + Lw.qkv),
+           *ctx = (int8_t *)(ws + Lw.ctx), *h8 = (int8_t *)(ws + Lw.h8), *g8 = (int8_t *)(ws + Lw.g8),
+           *pool = (int8_t *)(ws + Lw.pool);
+    int16_t *x = (int16_t *)(ws + Lw.xa), *y = (int16_t *)(ws + Lw.xb), *t16 = (int16_t *)(ws + Lw.xc);
+    float *zf = (float *)(ws + Lw.zf);
+    const int E = c.embed_dim;
+    int res = m->grid, L = res * res;
+    long long M = (long long)B * L;
+    const int Kp = c.in_chans * c.patch_size * c.patch_size;
+    int rc;
+#define RUN(call) do { rc = (call); if (rc != IVIT_OK) { if (h != m->h) snprintf(m->h->err, sizeof(m->h->err), "%s", h->err); return rc; } } while (0)
+    // PatchEmbed: conv -> qact_before_norm(8) -> norm (token-order sums) -> qact(16) -> qact1(16)
+    RUN(ivit_im2col_patch(h, images, B, c.in_chans, c.img_size, c.img_size, c.patch_size, patches));
+    RUN(ivit_linear_i8_requant(h, patches, P.pe.w, P.pe.b, P.pe.dy, 8, a8, (int)M, E, Kp));
+    RUN(ivit_widen_i8_i16(h, a8, y, M * E));
+    RUN(ivit_layernorm_tokenorder(h, y, M, E, P.s_bn, P.pn.bias_int, P.pn.sc, L, zf));
+    RUN(ivit_requant_f32(h, zf, P.pn.dy, E, nullptr, nullptr, 16, y, M, E));
+    RUN(ivit_requant_i16(h, y, P.dy_qact1, 1, nullptr, nullptr, 16, x, M, E));
+    int bi = 0;
+    for (int li = 0; li < c.num_layers; ++li) {
+        const int C = E << li, heads = c.num_heads[li];
+        for (int bj = 0; bj < c.depths[li]; ++bj, ++bi) {
+            const ivit_swin_block &b = m->blocks[bi];
+            const int shift = (bj % 2 == 0 || res <= c.window_size) ? 0 : c.window_size / 2;
+            RUN(swin_ln(m, h, x, M, C, b.s_in, b.n1, L, li == 0, a8));
+            RUN(ivit_linear_i8_requant(h, a8, b.qkv.w, b.qkv.b, b.qkv.dy, 8, qkv, (int)M, 3 * C, C));
+            RUN(ivit_window_attention_fused(h, qkv, b.dy_qk, b.dy_a, b.relb, b.s_softmax, b.dy_pv, ctx, B, res,
+                                            c.window_size, shift, heads, C / heads));
+            RUN(ivit_linear_i8_requant_residual(h, ctx, b.proj.w, b.proj.b, b.proj.dy, b.res1_main, b.res1_res, x, y, (int)M, C, C));
+            { int16_t *t = x; x = y; y = t; }
+            RUN(swin_ln(m, h, x, M, C, b.s_mid, b.n2, L, li == 0, a8));
+            RUN(ivit_linear_i8_requant(h, a8, b.fc1.w, b.fc1.b, b.fc1.dy, 8, h8, (int)M, c.mlp_ratio * C, C));
+            RUN(ivit_shiftgelu_requant_lut(h, h8, M, c.mlp_ratio * C, m->gelu_tab + (size_t)bi * 65536, g8));
+            RUN(ivit_linear_i8_requant_residual(h, g8, b.fc2.w, b.fc2.b, b.fc2.dy, b.res2_main, b.res2_res, x, y, (int)M, C, c.mlp_ratio * C));
+            { int16_t *t = x; x = y; y = t; }
+        }
+        if (li < c.num_layers - 1) {     // PatchMerging: gather -> LN(4C) -> qact1(8) -> reduction -> qact2(8)
+            const ivit_swin_merge &g = m->merges[li];
+            RUN(ivit_patch_merge_gather(h, x, 16, B, res, C, t16));
+            res /= 2;
+            L = res * res;
+            M = (long long)B * L;
+            RUN(swin_ln(m, h, t16, M, 4 * C, g.s_in, g.n, L, false, a8));
+            RUN(ivit_linear_i8_requant(h, a8, g.red.w, nullptr, g.red.dy, 8, ctx, (int)M, 2 * C, 4 * C));
+            RUN(ivit_widen_i8_i16(h, ctx, x, M * 2 * C));
+        }
+    }
+    const int C = E << (c.num_layers - 1);
+    RUN(swin_ln(m, h, x, M, C, P.s_norm_in, P.n, L, false, a8));
+    RUN(ivit_avgpool_requant(h, a8, B, L, C, P.dy_pool, pool));
+    RUN(ivit_linear_i8(h, pool, P.head_w, P.head_b, logits, B, c.num_classes, C));
+#undef RUN
+    return IVIT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ivit_swin_destroy(ivit_swin m) {
+    if (!m) return IVIT_ERR_INVALID;
+    for (auto sh : m->slice_h) ivit_destroy(sh);
+    for (auto ev : m->done) hipEventDestroy(ev);
+    for (auto st : m->streams) hipStreamDestroy(st);
+    if (m->fork) hipEventDestroy(m->fork);
+    if (m->gelu_tab) hipFree(m->gelu_tab);
+    delete m;
+    return IVIT_OK;
+}
+
+int ivit_swin_create(ivit_handle h, const ivit_swin_config *cfg, const ivit_swin_params *params, int max_slices,
+                     ivit_swin *out) {
+    CHECK_H(h);
+    REQUIRE(h, cfg && params && out && params->blocks_host, "null argument");
+    REQUIRE(h, cfg->num_layers >= 1 && cfg->num_layers <= 4 && cfg->embed_dim > 0 && cfg->patch_size > 0 &&
+                   cfg->img_size % cfg->patch_size == 0 && cfg->mlp_ratio > 0 && cfg->num_classes > 0,
+            "bad model configuration");
+    REQUIRE(h, cfg->num_layers == 1 || params->merges_host, "merges_host missing");
+    REQUIRE(h, max_slices >= 1 && max_slices <= 16, "max_slices must be in [1, 16]");
+    int nb = 0;
+    for (int li = 0; li < cfg->num_layers; ++li) {
+        if (cfg->window_size != 7 || cfg->num_heads[li] <= 0 || ((cfg->embed_dim << li) / cfg->num_heads[li]) != 32) {
+            snprintf(h->err, sizeof(h->err), "ivit_swin_create: built for window 7 and head dim 32");
+            return IVIT_ERR_UNSUPPORTED;
+        }
+        nb += cfg->depths[li];
+    }
+    const int grid = cfg->img_size / cfg->patch_size;
+    REQUIRE(h, (grid >> (cfg->num_layers - 1)) % 7 == 0 && grid % (7 << (cfg->num_layers - 1)) == 0,
+            "every stage resolution must be a multiple of the window");
+    ivit_swin_s *m = new ivit_swin_s();
+    m->h = h; m->cfg = *cfg; m->prm = *params;
+    m->blocks.assign(params->blocks_host, params->blocks_host + nb);
+    if (cfg->num_layers > 1) m->merges.assign(params->merges_host, params->merges_host + cfg->num_layers - 1);
+    m->grid = grid; m->nblocks = nb; m->gelu_tab = nullptr; m->max_slices = max_slices; m->fork = nullptr;
+    if (hipMalloc((void **)&m->gelu_tab, (size_t)nb * 65536) != hipSuccess) {
+        snprintf(h->err, sizeof(h->err), "ivit_swin_create: hipMalloc failed");
+        delete m;
+        return IVIT_ERR_HIP;
+    }
+    for (int i = 0; i < nb; ++i) {
+        int rc = ivit_shiftgelu_build_table(h, m->blocks[i].s_gelu, m->blocks[i].dy_gelu, m->gelu_tab + (size_t)i * 65536);
+        if (rc != IVIT_OK) { ivit_swin_destroy(m); return rc; }
+    }
+    if (max_slices > 1) {
+        hipEventCreateWithFlags(&m->fork, hipEventDisableTiming);
+        for (int i = 0; i < max_slices; ++i) {
+            hipStream_t st;
+            hipEvent_t ev;
+            if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+                snprintf(h->err, sizeof(h->err), "ivit_swin_create: stream/event creation failed");
+                ivit_swin_destroy(m);
+                return IVIT_ERR_HIP;
+            }
+            ivit_handle sh = nullptr;
+            ivit_create(&sh, h->device, st);
+            m->streams.push_back(st); m->done.push_back(ev); m->slice_h.push_back(sh);
+        }
+    }
+    *out = m;
+    return IVIT_OK;
+}
+
+int ivit_swin_workspace_bytes(ivit_swin m, int batch, int nslices, size_t *bytes) {
+    if (!m) return IVIT_ERR_INVALID;
+    REQUIRE(m->h, bytes && batch > 0 && nslices >= 1 && nslices <= m->max_slices && nslices <= batch, "bad arguments");
+    *bytes = swin_layout(m, max_slice(batch, nslices)).total * (size_t)nslices;
+    return IVIT_OK;
+}
+
+int ivit_swin_forward(ivit_swin m, const int8_t *images, int batch, int nslices, void *workspace, size_t bytes,
+                      int32_t *logits) {
+    if (!m) return IVIT_ERR_INVALID;
+    ivit_handle h = m->h;
+    size_t need = 0;
+    int rc = ivit_swin_workspace_bytes(m, batch, nslices, &need);
+    if (rc != IVIT_OK) return rc;
+    REQUIRE(h, images && logits && workspace && bytes >= need, "bad arguments / workspace too small");
+    REQUIRE(h, ((uintptr_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
+    const size_t img_bytes = (size_t)m->cfg.in_chans * m->cfg.img_size * m->cfg.img_size;
+    const size_t stride = swin_layout(m, max_slice(batch, nslices)).total;
+    if (nslices == 1) return swin_run_slice(m, h, images, batch, (char *)workspace, logits);
+    if (hipEventRecord(m->fork, h->stream) != hipSuccess) return IVIT_ERR_HIP;
+    for (int i = 0; i < nslices; ++i) {
+        const int b0 = slice_begin(batch, nslices, i), b1 = slice_begin(batch, nslices, i + 1);
+        if (hipStreamWaitEvent(m->streams[i], m->fork, 0) != hipSuccess) return IVIT_ERR_HIP;
+        rc = swin_run_slice(m, m->slice_h[i], images + (size_t)b0 * img_bytes, b1 - b0, (char *)workspace + stride * (size_t)i,
+                            logits + (size_t)b0 * m->cfg.num_classes);
+        if (rc != IVIT_OK) return rc;
+        if (hipEventRecord(m->done[i], m->streams[i]) != hipSuccess) return IVIT_ERR_HIP;
+    }
+    for (int i = 0; i < nslices; ++i)
+        if (hipStreamWaitEvent(h->stream, m->done[i], 0) != hipSuccess) return IVIT_ERR_HIP;
+    return IVIT_OK;
+}
+
+int ivit_swin_graph_create(ivit_swin m, const int8_t *images, int batch, int nslices, void *workspace, size_t bytes,
+                           int32_t *logits, ivit_graph *out) {
+    if (!m) return IVIT_ERR_INVALID;
+    ivit_handle h = m->h;
+    REQUIRE(h, out, "null argument");
+    REQUIRE(h, h->stream != nullptr, "graph capture needs a non-default stream on the handle");
+    hipError_t e = hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed);
+    if (e != hipSuccess) { snprintf(h->err, sizeof(h->err), "begin capture: %s", hipGetErrorString(e)); return IVIT_ERR_HIP; }
+    int rc = ivit_swin_forward(m, images, batch, nslices, workspace, bytes, logits);
+    hipGraph_t graph = nullptr;
+    e = hipStreamEndCapture(h->stream, &graph);
+    if (rc != IVIT_OK) { if (graph) hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess || !graph) { snprintf(h->err, sizeof(h->err), "end capture: %s", hipGetErrorString(e)); return IVIT_ERR_HIP; }
+    hipGraphExec_t exec = nullptr;
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) { hipGraphDestroy(graph); snprintf(h->err, sizeof(h->err), "instantiate: %s", hipGetErrorString(e)); return IVIT_ERR_HIP; }
+    ivit_graph_s *g = new ivit_graph_s();
+    g->h = h; g->graph = graph; g->exec = exec;
+    *out = g;
     return IVIT_OK;
 }
 

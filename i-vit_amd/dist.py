@@ -44,3 +44,28 @@ def build_engine_broadcast(cfg, weights, scales, device, rank, world):
         consts, f32 = freeze_vit(cfg, weights, scales)
     blob, table, f32 = broadcast_constants(consts, f32, rank, world, device)
     return ViTEngine(cfg, None, f32, device=device, blob=blob, table=table)
+
+
+def broadcast_packed(packed, rank, world, device):
+    """(blob, table, host) of any engine from rank 0 to every rank: the table / host scalars as one small
+    object, the byte blob as ONE tensor broadcast (RCCL ring over xGMI on GPUs)."""
+    if world == 1:
+        blob, table, host = packed
+        return torch.from_numpy(blob).to(device), table, host
+    meta, blob_t = [None], None
+    if rank == 0:
+        blob, table, host = packed
+        meta = [(table, host, int(blob.size))]
+        blob_t = torch.from_numpy(blob).to(device)
+    dist.broadcast_object_list(meta, src=0)
+    table, host, nbytes = meta[0]
+    if rank != 0:
+        blob_t = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    dist.broadcast(blob_t, src=0)
+    return blob_t, table, host
+
+
+def build_swin_engine_broadcast(cfg, weights, scales, device, rank, world):
+    from .swin_engine import SwinEngine, freeze_swin, pack_swin_constants
+    packed = pack_swin_constants(freeze_swin(cfg, weights, scales)) if rank == 0 else None
+    return SwinEngine(cfg, None, None, device=device, packed=broadcast_packed(packed, rank, world, device))

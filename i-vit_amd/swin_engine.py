@@ -20,6 +20,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from .engine import pack_constants
 from .freeze import dyadic, layernorm_constants, quantize, quantize_bias, quantize_weight
 
 _P = ctypes.c_void_p
@@ -116,27 +117,45 @@ def freeze_swin(cfg, weights, scales):
     return c
 
 
+DEVICE_DYADICS = ("dy_qact1",)          # [1,2] tables the kernels read through a pointer
+
+
+def pack_swin_constants(consts):
+    """freeze_swin output -> (byte blob, table, host scalars): the unit one RCCL broadcast carries.
+    Arrays go into the blob; by-value dyadics and fp32 scalars travel in `host` (a small picklable dict)."""
+    arrays, host = {}, {}
+    for k, v in consts.items():
+        if isinstance(v, np.ndarray) and v.dtype == np.float64 and v.shape == (1, 2) and k not in DEVICE_DYADICS:
+            host[k] = ("dy", float(v[0, 0]), float(v[0, 1]))
+        elif isinstance(v, np.ndarray) and v.ndim >= 1:
+            arrays[k] = v
+        else:
+            host[k] = ("f", float(np.float32(v)))
+    blob, table = pack_constants(arrays)
+    return blob, table, host
+
+
 class SwinEngine:
-    def __init__(self, cfg, weights, scales, device="cuda:0"):
+    def __init__(self, cfg, weights, scales, device="cuda:0", packed=None):
+        """weights/scales: freeze here (rank 0) — or `packed` = (blob, table, host) received from a broadcast."""
         if not torch.cuda.is_available():
             raise _lib.IvitError("SwinEngine needs a HIP device; the product path has no CPU fallback")
         self.cfg, self.device = cfg, torch.device(device)
         torch.cuda.set_device(self.device)
         if cfg.window_size != 7 or any((cfg.embed_dim * 2 ** i) // h != 32 for i, h in enumerate(cfg.num_heads)):
             raise _lib.IvitError("the fused windowed attention is built for window 7 / head dim 32")
-        consts = freeze_swin(cfg, weights, scales)
-        # by-value dyadics ([1,2] float64), device arrays, host fp32 scalars
-        self.f, self.dy, self.t = {}, {}, {}
-        for k, v in consts.items():
-            if isinstance(v, np.ndarray) and v.dtype == np.float64 and v.shape == (1, 2):
-                self.dy[k] = _lib.Dyadic(float(v[0, 0]), float(v[0, 1]))
-            elif isinstance(v, np.ndarray) and v.ndim >= 1:
-                self.t[k] = torch.from_numpy(np.ascontiguousarray(v)).to(self.device)
-            else:
-                self.f[k] = float(np.float32(v))
-        self.head_scale = np.asarray(consts["head.scale"], np.float32)
+        blob, table, host = packed if packed is not None else pack_swin_constants(freeze_swin(cfg, weights, scales))
+        self.table, self.host_consts = table, host
+        self.blob = torch.from_numpy(blob).to(self.device) if isinstance(blob, np.ndarray) else blob.to(self.device)
+        o, dt, shp = table["head.scale"]
+        self.head_scale = self.blob[o:o + 4 * int(np.prod(shp))].cpu().numpy().view(np.float32).copy()
+        self.f = {k: v[1] for k, v in host.items() if v[0] == "f"}
+        self.dy = {k: _lib.Dyadic(v[1], v[2]) for k, v in host.items() if v[0] == "dy"}
+        self.t = _BlobView(self.blob, table)
         self.h = _lib.Handle(self.device.index or 0, torch.cuda.current_stream(self.device).cuda_stream)
-        # per-layer ShiftGELU(+requant) tables
+        self._build_native()
+        # per-layer ShiftGELU(+requant) tables for forward_ops (the native runner owns its own copies)
+        cfg = self.cfg
         self.gelu = {}
         for li, depth in enumerate(cfg.depths):
             for bj in range(depth):
@@ -146,15 +165,68 @@ class SwinEngine:
                 self.gelu[p] = tab
         self._ws = {}
 
+    MAX_SLICES = 8
+
     def ptr(self, name):
-        return _P(self.t[name].data_ptr())
+        return _P(self.t.addr(name))
 
     def _dyp(self, name):
-        """device pointer to a per-channel dyadic table, or to a 1-entry table for by-pointer scalars"""
-        if name not in self.t:
-            d = self.dy[name]
-            self.t[name] = torch.tensor([[d.m, d.r]], dtype=torch.float64, device=self.device)
-        return _P(self.t[name].data_ptr())
+        return self.ptr(name)
+
+    def _build_native(self):
+        """ivit_swin_create: device pointers into the blob + host scalars -> one C call per batch"""
+        cfg, L, f, dy = self.cfg, _lib, self.f, self.dy
+        a = lambda name: self.t.addr(name) if name in self.table else None
+        ln = lambda p: L.LnParams(a(p + ".bias_int"), a(p + ".sc"), a(p + ".dy"))
+        lin = lambda p: L.LinParams(a(p + ".w"), a(p + ".b"), a(p + ".dy"))
+        nb = sum(cfg.depths)
+        blocks = (L.SwinBlock * nb)()
+        merges = (L.SwinMerge * max(1, cfg.num_layers - 1))()
+        i = 0
+        for li, depth in enumerate(cfg.depths):
+            for bj in range(depth):
+                p, b = f"layers.{li}.blocks.{bj}.", blocks[i]
+                b.s_in, b.n1, b.qkv = f[p + "s_in"], ln(p + "norm1"), lin(p + "attn.qkv")
+                b.dy_qk, b.dy_a, b.relb = dy[p + "attn.dy_qk"], dy[p + "attn.dy_a"], a(p + "attn.relb")
+                b.s_softmax, b.dy_pv, b.proj = f[p + "attn.s_softmax"], dy[p + "attn.dy_pv"], lin(p + "attn.proj")
+                b.res1_main, b.res1_res = dy[p + "res1.dy_main"], dy[p + "res1.dy_res"]
+                b.s_mid, b.n2, b.fc1 = f[p + "s_mid"], ln(p + "norm2"), lin(p + "mlp.fc1")
+                b.s_gelu, b.dy_gelu, b.fc2 = f[p + "mlp.s_gelu"], dy[p + "mlp.dy_gelu"], lin(p + "mlp.fc2")
+                b.res2_main, b.res2_res = dy[p + "res2.dy_main"], dy[p + "res2.dy_res"]
+                i += 1
+            if li < cfg.num_layers - 1:
+                p, g = f"layers.{li}.downsample.", merges[li]
+                g.s_in, g.n, g.red = f[p + "s_in"], ln(p + "norm"), lin(p + "reduction")
+        prm = L.SwinParams()
+        prm.pe, prm.s_bn, prm.pn, prm.dy_qact1 = lin("patch_embed.proj"), f["patch_embed.s_bn"], ln("patch_embed.norm"), a("dy_qact1")
+        prm.blocks_host = ctypes.cast(blocks, ctypes.POINTER(L.SwinBlock))
+        prm.merges_host = ctypes.cast(merges, ctypes.POINTER(L.SwinMerge))
+        prm.s_norm_in, prm.n, prm.dy_pool = f["norm.s_in"], ln("norm"), dy["dy_pool"]
+        prm.head_w, prm.head_b = a("head.w"), a("head.b")
+        c = L.SwinConfigC(cfg.img_size, cfg.patch_size, cfg.in_chans, cfg.embed_dim, cfg.num_layers, cfg.window_size,
+                          int(cfg.mlp_ratio), cfg.num_classes, (ctypes.c_int * 4)(*(list(cfg.depths) + [0] * 4)[:4]),
+                          (ctypes.c_int * 4)(*(list(cfg.num_heads) + [0] * 4)[:4]))
+        self.model = _P()
+        self.h._check(self.h.lib.ivit_swin_create(self.h.h, ctypes.byref(c), ctypes.byref(prm), self.MAX_SLICES,
+                                                  ctypes.byref(self.model)), "ivit_swin_create")
+        self._native_ws = {}
+
+    def __del__(self):
+        try:
+            if getattr(self, "model", None):
+                self.h.lib.ivit_swin_destroy(self.model)
+                self.model = None
+        except Exception:
+            pass
+
+    def _native_buffers(self, B, nslices):
+        key = (B, nslices)
+        if key not in self._native_ws:
+            n = ctypes.c_size_t()
+            self.h._check(self.h.lib.ivit_swin_workspace_bytes(self.model, B, nslices, ctypes.byref(n)), "ivit_swin_workspace_bytes")
+            self._native_ws[key] = (torch.empty(n.value, dtype=torch.uint8, device=self.device),
+                                    torch.empty(B, self.cfg.num_classes, dtype=torch.int32, device=self.device))
+        return self._native_ws[key]
 
     def workspace(self, B, key=None):
         if (B, key) in self._ws:
@@ -181,6 +253,17 @@ class SwinEngine:
         """images int8 [B, C, H, W] (scale qact_input) -> int32 logits [B, num_classes].
         nslices > 1: independent batch slices on separate HIP streams (VALU-bound attention / LayerNorm of
         one slice share the chip with the GEMMs of another); same integers."""
+        assert images.dtype == torch.int8 and images.is_contiguous() and images.device == self.device
+        self.h.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        B = images.shape[0]
+        nslices = max(1, min(int(nslices), B, self.MAX_SLICES))
+        ws, logits = self._native_buffers(B, nslices)
+        self.h._check(self.h.lib.ivit_swin_forward(self.model, _P(images.data_ptr()), B, nslices, _P(ws.data_ptr()),
+                                                   ws.numel(), _P(logits.data_ptr())), "ivit_swin_forward")
+        return logits
+
+    def forward_ops(self, images, nslices=1):
+        """the same forward issued one C-ABI call per operator from Python (per-operator timing)"""
         if nslices > 1 and images.shape[0] >= nslices:
             return self._forward_sliced(images, nslices)
         return self._forward_one(images, None)
@@ -259,17 +342,27 @@ class SwinEngine:
         return ws["logits"]
 
     def capture(self, images, nslices=1):
-        """hipGraph of one forward on fixed buffers (every C-ABI call is capturable: nothing allocates or
-        synchronises).  Returns a callable that replays it and returns the logits tensor."""
-        self.forward(images, nslices)           # allocates the workspaces outside the capture
+        """hipGraph of one forward on fixed buffers (ivit_swin_graph_create); returns a replay callable."""
+        B = images.shape[0]
+        nslices = max(1, min(int(nslices), B, self.MAX_SLICES))
+        ws, logits = self._native_buffers(B, nslices)
+        if not hasattr(self, "_gstream"):
+            self._gstream = torch.cuda.Stream(self.device)
         torch.cuda.synchronize(self.device)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            out = self.forward(images, nslices)
+        self.h.set_stream(self._gstream.cuda_stream)
+        g = _P()
+        self.h._check(self.h.lib.ivit_swin_graph_create(self.model, _P(images.data_ptr()), B, nslices, _P(ws.data_ptr()),
+                                                        ws.numel(), _P(logits.data_ptr()), ctypes.byref(g)), "ivit_swin_graph_create")
+        self._graphs = getattr(self, "_graphs", []) + [g]
+        lib, gs, dev = self.h.lib, self._gstream, self.device
 
         def replay():
-            g.replay()
-            return out
+            cur = torch.cuda.current_stream(dev)
+            gs.wait_stream(cur)
+            self.h.set_stream(gs.cuda_stream)
+            self.h._check(lib.ivit_graph_launch(g), "ivit_graph_launch")
+            cur.wait_stream(gs)
+            return logits
         return replay
 
     def _ln(self, x16, M, C, s_in, name, L, token_order, out8):
@@ -281,3 +374,15 @@ class SwinEngine:
             self.h.call("ivit_layernorm_requant", P(x16), M, C, C, s_in, self.ptr(name + ".bias_int"),
                         self.ptr(name + ".sc"), self.ptr(name + ".dy"), P(out8))
 
+
+class _BlobView:
+    """name -> device address / tensor view inside the packed constants blob"""
+
+    def __init__(self, blob, table):
+        self.blob, self.table = blob, table
+
+    def __contains__(self, name):
+        return name in self.table
+
+    def addr(self, name):
+        return self.blob.data_ptr() + self.table[name][0]

@@ -240,6 +240,56 @@ int ivit_vit_graph_create(ivit_vit m, const int8_t *images, int batch, int nslic
 int ivit_graph_launch(ivit_graph g);
 int ivit_graph_destroy(ivit_graph g);
 
+/* ---- a12  whole-model runner for Swin: SwinTransformer.forward (swin_quant.py:539-564) with
+ * SwinTransformerBlock.forward (:251-301), WindowAttention.forward (:121-169), PatchMerging.forward
+ * (:328-349) and PatchEmbed.forward (layers_quant.py:184-196) chained natively; activations stay in natural
+ * token order, roll / window partition / reverse are index arithmetic inside ivit_window_attention_fused.
+ * Built for window 7 and head dim 32 (every reference factory).  Same conventions as ivit_vit_*.      */
+typedef struct ivit_ln_params { const float *bias_int; const float *sc; const ivit_dyadic *dy; } ivit_ln_params;
+typedef struct ivit_lin_params { const int8_t *w; const int32_t *b; const ivit_dyadic *dy; } ivit_lin_params;
+
+typedef struct ivit_swin_config {
+    int img_size, patch_size, in_chans, embed_dim, num_layers, window_size, mlp_ratio, num_classes;
+    int depths[4];
+    int num_heads[4];
+} ivit_swin_config;
+
+typedef struct ivit_swin_block {
+    float s_in; ivit_ln_params n1;                         /* norm1 -> qact1 (:253-255)                         */
+    ivit_lin_params qkv;                                   /* attn.qkv -> attn.qact1 (:123-124)                 */
+    ivit_dyadic dy_qk, dy_a; const int16_t *relb;          /* qact_attn1; qact2 with the bias identity (:133-149) */
+    float s_softmax; ivit_dyadic dy_pv;                    /* Shiftmax 8 bit (:151-157); attn.v -> qact3 (:159-162) */
+    ivit_lin_params proj;                                  /* attn.proj -> attn.qact4 (:163-164)                */
+    ivit_dyadic res1_main, res1_res;                       /* qact2 with identity (:289)                        */
+    float s_mid; ivit_ln_params n2;                        /* norm2 -> qact3 (:291-292)                         */
+    ivit_lin_params fc1; float s_gelu; ivit_dyadic dy_gelu; ivit_lin_params fc2;   /* mlp (layers_quant.py:144-153) */
+    ivit_dyadic res2_main, res2_res;                       /* qact4 with identity (:296)                        */
+} ivit_swin_block;
+
+typedef struct ivit_swin_merge {                           /* PatchMerging: norm -> qact1 -> reduction -> qact2 */
+    float s_in; ivit_ln_params n; ivit_lin_params red;
+} ivit_swin_merge;
+
+typedef struct ivit_swin_params {
+    ivit_lin_params pe; float s_bn;                        /* patch_embed.proj -> qact_before_norm (8 bit)      */
+    ivit_ln_params pn; const ivit_dyadic *dy_qact1;        /* patch_embed.norm -> qact (16); qact1 (16), 1 entry */
+    const ivit_swin_block *blocks_host;                    /* HOST array [sum(depths)], stage-major             */
+    const ivit_swin_merge *merges_host;                    /* HOST array [num_layers - 1]                       */
+    float s_norm_in; ivit_ln_params n;                     /* norm -> qact2                                     */
+    ivit_dyadic dy_pool;                                   /* avgpool -> qact3                                  */
+    const int8_t *head_w; const int32_t *head_b;
+} ivit_swin_params;
+
+typedef struct ivit_swin_s *ivit_swin;
+int ivit_swin_create(ivit_handle h, const ivit_swin_config *cfg, const ivit_swin_params *params,
+                     int max_slices, ivit_swin *out);
+int ivit_swin_destroy(ivit_swin m);
+int ivit_swin_workspace_bytes(ivit_swin m, int batch, int nslices, size_t *bytes);
+int ivit_swin_forward(ivit_swin m, const int8_t *images, int batch, int nslices, void *workspace,
+                      size_t bytes, int32_t *logits);
+int ivit_swin_graph_create(ivit_swin m, const int8_t *images, int batch, int nslices, void *workspace,
+                           size_t bytes, int32_t *logits, ivit_graph *out);
+
 /* ---- a12  Swin-specific operators (models/swin_quant.py)
  * IntSoftmax on `attn + mask` (:151-156): float mask [nW, n, n] (0 / -100.0) added to fl(Q*s)
  * before the division by s; row r of the flattened [B_, H, n] rows uses window (r/(H*n)) % nW.

@@ -63,6 +63,37 @@ def test_broadcast_and_sharding_world2():
     assert hashlib.sha256(blob.tobytes()).hexdigest() == d0
 
 
+def _swin_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ivit_amd.swin_engine import freeze_swin, pack_swin_constants
+    g = load_golden("micro_swin_b2.npz")
+    cfg = iv.SWIN_CONFIGS[str(g["cfg_name"])]
+    packed = None
+    if rank == 0:
+        packed = pack_swin_constants(freeze_swin(cfg, iv.make_swin_weights(cfg, int(g["seed"])), golden_scales(g)))
+    blob, table, host = ivdist.broadcast_packed(packed, rank, world, "cpu")
+    q.put((rank, hashlib.sha256(blob.numpy().tobytes()).hexdigest(), len(table), sorted(host)[:4], host["dy_pool"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_swin_constants_broadcast_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_swin_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1:] == res[1][1:]
+    assert res[0][4][0] == "dy" and res[0][2] > 50
+
+
 def test_shard_range_covers_batch():
     for total in (1, 7, 256, 513):
         for world in (1, 2, 3, 8):

@@ -494,9 +494,10 @@ def test_swin_engine_golden_logits(fname):
     w = iv.make_swin_weights(cfg, int(g["seed"]))
     eng = SwinEngine(cfg, w, golden_scales(g))
     imgs = iv.make_images_int8(cfg, int(g["batch"]), int(g["images_seed"]))
-    logits = eng.forward(dev(imgs)).cpu().numpy()
+    logits = eng.forward(dev(imgs)).cpu().numpy()                    # native runner (ivit_swin_forward)
     assert np.array_equal(logits, g["logits_int"])
     assert np.array_equal(eng.head_scale, g["logits_scale"])
+    assert np.array_equal(eng.forward_ops(dev(imgs)).cpu().numpy(), g["logits_int"])   # one C-ABI call per operator
     if fname.startswith("micro"):
         from oracle import oracle as orc
         imgs2 = iv.make_images_int8(cfg, 5, seed=123)

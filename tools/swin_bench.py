@@ -34,7 +34,7 @@ for batch in [int(x) for x in os.environ.get("SW_BATCH", "1,64,256").split(",")]
         if name.startswith("ivit_linear_i8_requant"): name += " MNK=" + "x".join(str(v) for v in a[-3:])
         recs.append((name, e0, e1))
     eng.h.call = call
-    eng.forward(imgs); torch.cuda.synchronize(); eng.h.call = orig
+    eng.forward_ops(imgs); torch.cuda.synchronize(); eng.h.call = orig
     per = {}
     for name, e0, e1 in recs:
         d = per.setdefault(name, [0.0, 0]); d[0] += e0.elapsed_time(e1); d[1] += 1
