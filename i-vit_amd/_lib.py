@@ -127,6 +127,7 @@ SIGNATURES = {
     "ivit_requant_i16": [_P, _P, _P, _I, _P, _P, _I, _P, _L, _I],
     "ivit_layernorm_tokenorder_requant": [_P, _P, _L, _I, _F, _P, _P, _P, _I, _P],
     "ivit_window_attention_fused": [_P, _P, Dyadic, Dyadic, _P, _F, Dyadic, _P, _I, _I, _I, _I, _I, _I],
+    "ivit_mlp_fused": [_P, _P, _P, _P, _P, _P, _P, _P, _P, Dyadic, Dyadic, _P, _P, _L, _I, _I],
     "ivit_patch_merge_gather": [_P, _P, _I, _I, _I, _I, _P],
     "ivit_widen_i8_i16": [_P, _P, _P, _L],
     "ivit_swin_create": [_P, ctypes.POINTER(SwinConfigC), ctypes.POINTER(SwinParams), _I, ctypes.POINTER(_P)],

@@ -578,6 +578,32 @@ int ivit_window_attention_fused(ivit_handle h, const int8_t *qkv, ivit_dyadic dy
     return IVIT_OK;
 }
 
+int ivit_mlp_fused(ivit_handle h, const int8_t *x, const int8_t *w1, const int32_t *b1, const ivit_dyadic *dy1,
+                   const int8_t *gelu_table, const int8_t *w2, const int32_t *b2, const ivit_dyadic *dy2,
+                   ivit_dyadic dy_main, ivit_dyadic dy_res, const int16_t *residual, int16_t *out, int64_t M, int C,
+                   int hidden) {
+    CHECK_H(h);
+    REQUIRE(h, x && w1 && dy1 && gelu_table && w2 && dy2 && residual && out && M > 0, "bad arguments");
+    if (C != MF_C || hidden != MF_HD) {
+        snprintf(h->err, sizeof(h->err), "%s: built for C = 96, hidden = 384 (weights resident in LDS)", __func__);
+        return IVIT_ERR_UNSUPPORTED;
+    }
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void *)swin_mlp_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MF_SMEM);
+        if (e != hipSuccess) { snprintf(h->err, sizeof(h->err), "mlp_fused attr: %s", hipGetErrorString(e)); return IVIT_ERR_HIP; }
+        attr = true;
+    }
+    MlpFusedArgs a;
+    a.x = x; a.w1 = w1; a.b1 = b1; a.dy1 = dy1; a.tab = gelu_table; a.w2 = w2; a.b2 = b2; a.dy2 = dy2;
+    a.dy_main = dy_main; a.dy_res = dy_res; a.residual = residual; a.out = out; a.M = M;
+    const long long ntiles = (M + MF_BM - 1) / MF_BM;
+    const unsigned grid = (unsigned)(ntiles < h->num_cu ? ntiles : h->num_cu);
+    swin_mlp_fused_kernel<<<grid, 512, MF_SMEM, h->stream>>>(a);
+    LAUNCH_CHECK(h);
+    return IVIT_OK;
+}
+
 int ivit_patch_merge_gather(ivit_handle h, const void *x, int in_bits, int B, int R, int C, int16_t *out) {
     CHECK_H(h);
     REQUIRE(h, x && out && B > 0 && R > 0 && (R % 2) == 0 && C > 0 && (C % 8) == 0, "bad arguments (C must be a multiple of 8)");

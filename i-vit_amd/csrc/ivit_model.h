@@ -281,6 +281,7 @@ struct ivit_swin_s {
     std::vector<ivit_swin_block> blocks;
     std::vector<ivit_swin_merge> merges;
     int grid, nblocks;
+    bool fused_mlp;                   // IVIT_SWIN_FUSED_MLP=0 disables the stage-0 fused MLP (A/B, tests)
     int8_t *gelu_tab;                 // [nblocks][65536]
     int max_slices;
     std::vector<ivit_handle> slice_h;
@@ -355,9 +356,14 @@ int swin_run_slice(const ivit_swin_s *m, ivit_handle h, const int8_t *images, in
             RUN(ivit_linear_i8_requant_residual(h, ctx, b.proj.w, b.proj.b, b.proj.dy, b.res1_main, b.res1_res, x, y, (int)M, C, C));
             { int16_t *t = x; x = y; y = t; }
             RUN(swin_ln(m, h, x, M, C, b.s_mid, b.n2, L, li == 0, a8));
-            RUN(ivit_linear_i8_requant(h, a8, b.fc1.w, b.fc1.b, b.fc1.dy, 8, h8, (int)M, c.mlp_ratio * C, C));
-            RUN(ivit_shiftgelu_requant_lut(h, h8, M, c.mlp_ratio * C, m->gelu_tab + (size_t)bi * 65536, g8));
-            RUN(ivit_linear_i8_requant_residual(h, g8, b.fc2.w, b.fc2.b, b.fc2.dy, b.res2_main, b.res2_res, x, y, (int)M, C, c.mlp_ratio * C));
+            if (C == 96 && c.mlp_ratio == 4 && m->fused_mlp) {     // narrow stage: hidden tensor stays in LDS
+                RUN(ivit_mlp_fused(h, a8, b.fc1.w, b.fc1.b, b.fc1.dy, m->gelu_tab + (size_t)bi * 65536, b.fc2.w, b.fc2.b,
+                                   b.fc2.dy, b.res2_main, b.res2_res, x, y, M, C, 4 * C));
+            } else {
+                RUN(ivit_linear_i8_requant(h, a8, b.fc1.w, b.fc1.b, b.fc1.dy, 8, h8, (int)M, c.mlp_ratio * C, C));
+                RUN(ivit_shiftgelu_requant_lut(h, h8, M, c.mlp_ratio * C, m->gelu_tab + (size_t)bi * 65536, g8));
+                RUN(ivit_linear_i8_requant_residual(h, g8, b.fc2.w, b.fc2.b, b.fc2.dy, b.res2_main, b.res2_res, x, y, (int)M, C, c.mlp_ratio * C));
+            }
             { int16_t *t = x; x = y; y = t; }
         }
         if (li < c.num_layers - 1) {     // PatchMerging: gather -> LN(4C) -> qact1(8) -> reduction -> qact2(8)
@@ -419,6 +425,7 @@ int ivit_swin_create(ivit_handle h, const ivit_swin_config *cfg, const ivit_swin
     m->blocks.assign(params->blocks_host, params->blocks_host + nb);
     if (cfg->num_layers > 1) m->merges.assign(params->merges_host, params->merges_host + cfg->num_layers - 1);
     m->grid = grid; m->nblocks = nb; m->gelu_tab = nullptr; m->max_slices = max_slices; m->fork = nullptr;
+    { const char *e = getenv("IVIT_SWIN_FUSED_MLP"); m->fused_mlp = e ? atoi(e) != 0 : true; }
     if (hipMalloc((void **)&m->gelu_tab, (size_t)nb * 65536) != hipSuccess) {
         snprintf(h->err, sizeof(h->err), "ivit_swin_create: hipMalloc failed");
         delete m;

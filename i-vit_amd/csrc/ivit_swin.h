@@ -424,3 +424,195 @@ __global__ __launch_bounds__(256) void widen_i8_i16_kernel(const int8_t *__restr
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
         out[i] = (int16_t)x[i];
 }
+
+// ---------------------------------------------------------------------------
+// a9 for narrow stages: Mlp.forward (layers_quant.py:144-153) + the block's closing QuantAct with identity
+// (swin_quant.py:293-296) in ONE kernel for C = 96, hidden = 384 (Swin-T/S stage 0):
+//     fc1 -> qact_gelu(8) -> ShiftGELU -> qact1(8) -> fc2 -> qact2(16) -> qact4(16, + identity)
+// Stage 0 is HBM-bound as separate kernels (the hidden tensor is 4x the activations: 308 MB per launch at
+// 256 images, written once and read twice); here it never leaves the LDS.  One persistent workgroup per CU
+// keeps BOTH weight matrices resident in LDS (2 x 36 KB) and walks 64-token tiles:
+//   S1  fc1 with v_mfma_i32_32x32x32_i8 (24 sub-tiles over 8 waves), requant to int8 straight into the
+//       fc2 B-fragment layout, per-token max of the hidden row via LDS ds_max;
+//   S2  one 256-byte ShiftGELU table row per token (selected by its row max) copied into LDS;
+//   S3  table gathers in place;   S4  fc2 (6 sub-tiles, K = 384), per-channel requant to 16 bit, then the
+//       identity requant-add and 16-byte stores.
+// Operand tiles are stored chunk-major ([k/32][row][32 B]) so every fragment read is one contiguous 1 KB.
+struct MlpFusedArgs {
+    const int8_t *x;          // [M, 96]  LN2 output
+    const int8_t *w1; const int32_t *b1; const ivit_dyadic *dy1;   // fc1 [384, 96] -> 8 bit
+    const int8_t *tab;        // ShiftGELU(+requant) table [256][256]
+    const int8_t *w2; const int32_t *b2; const ivit_dyadic *dy2;   // fc2 [96, 384] -> 16 bit
+    ivit_dyadic dy_main, dy_res;
+    const int16_t *residual;  // [M, 96]
+    int16_t *out;             // [M, 96]
+    long long M;
+};
+
+#define MF_C 96
+#define MF_HD 384
+#define MF_BM 64
+#define MF_W1 0
+#define MF_W2 (MF_W1 + MF_HD * MF_C)                 // 36864
+#define MF_X (MF_W2 + MF_C * MF_HD)                  // 73728: 2 x 6144
+#define MF_H (MF_X + 2 * MF_BM * MF_C)               // 86016: 24576
+#define MF_ROWS (MF_H + MF_BM * MF_HD)               // 110592: 16384
+#define MF_C1 (MF_ROWS + MF_BM * 256)                // 126976: 384 doubles
+#define MF_B1 (MF_C1 + MF_HD * 8)                    // 130048: 384 ints
+#define MF_C2 (MF_B1 + MF_HD * 4)                    // 131584: 96 doubles
+#define MF_B2 (MF_C2 + MF_C * 8)                     // 132352: 96 ints
+#define MF_MAX (MF_B2 + MF_C * 4)                    // 132736: 64 ints
+#define MF_SMEM (MF_MAX + MF_BM * 4)                 // 132992
+
+__global__ __launch_bounds__(512) void swin_mlp_fused_kernel(MlpFusedArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    double *sC1 = reinterpret_cast<double *>(sm + MF_C1), *sC2 = reinterpret_cast<double *>(sm + MF_C2);
+    int *sB1 = reinterpret_cast<int *>(sm + MF_B1), *sB2 = reinterpret_cast<int *>(sm + MF_B2);
+    int *sMax = reinterpret_cast<int *>(sm + MF_MAX);
+
+    // ---- one-off: weights -> LDS in fragment (chunk-major) layout, constants
+    for (int i = tid; i < MF_HD * MF_C / 16; i += 512) {          // W1 [384][96]: 6 chunks of 16 B per row
+        const int n = i / 6, c16 = i - n * 6, kc = c16 >> 1, hh = c16 & 1;
+        *reinterpret_cast<v4i *>(sm + MF_W1 + kc * (MF_HD * 32) + n * 32 + hh * 16) =
+            *reinterpret_cast<const v4i *>(p.w1 + n * MF_C + c16 * 16);
+    }
+    for (int i = tid; i < MF_C * MF_HD / 16; i += 512) {          // W2 [96][384]: 24 chunks per row
+        const int n = i / 24, c16 = i - n * 24, kc = c16 >> 1, hh = c16 & 1;
+        *reinterpret_cast<v4i *>(sm + MF_W2 + kc * (MF_C * 32) + n * 32 + hh * 16) =
+            *reinterpret_cast<const v4i *>(p.w2 + n * MF_HD + c16 * 16);
+    }
+    if (tid < MF_HD) { sC1[tid] = p.dy1[tid].m * p.dy1[tid].r; sB1[tid] = p.b1 ? p.b1[tid] : 0; }
+    if (tid < MF_C) { sC2[tid] = p.dy2[tid].m * p.dy2[tid].r; sB2[tid] = p.b2 ? p.b2[tid] : 0; }
+    const double cm = p.dy_main.m * p.dy_main.r, cr = p.dy_res.m * p.dy_res.r;
+
+    const long long ntiles = (p.M + MF_BM - 1) / MF_BM;
+    auto issue_x = [&](long long tile, int buf) {                 // 6 pieces of 1 KB: (kc, mt); waves 0..5
+        if (wave < 6) {
+            const int kc = wave >> 1, mt = wave & 1;
+            const long long t = min(tile * MF_BM + mt * 32 + l31, p.M - 1);
+            const int8_t *src = p.x + t * MF_C + kc * 32 + half * 16;
+            char *dst = sm + MF_X + buf * (MF_BM * MF_C) + (kc * 2 + mt) * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        }
+    };
+    long long tile = blockIdx.x;
+    if (tile < ntiles) issue_x(tile, 0);
+    int buf = 0;
+    for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+        if (tid < MF_BM) sMax[tid] = -128;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();                                          // X(tile) landed; H / rows free again
+        if (tile + gridDim.x < ntiles) issue_x(tile + gridDim.x, buf ^ 1);
+        const char *sX = sm + MF_X + buf * (MF_BM * MF_C);
+        // ---- S1: fc1, 3 (n-tile, m-tile) units per wave
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int unit = wave * 3 + u, nt = unit >> 1, mt = unit & 1;
+            v16i_sw acc;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const v4i b4 = *reinterpret_cast<const v4i *>(sB1 + nt * 32 + g * 8 + half * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[g * 4 + e] = b4[e];
+            }
+#pragma unroll
+            for (int kc = 0; kc < 3; ++kc) {
+                const v4i wf = *reinterpret_cast<const v4i *>(sm + MF_W1 + kc * (MF_HD * 32) + (nt * 32 + l31) * 32 + half * 16);
+                const v4i xf = *reinterpret_cast<const v4i *>(sX + (kc * 2 + mt) * 1024 + lane * 16);
+                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf, xf, acc, 0, 0, 0);
+            }
+            int mx = -128;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n0 = nt * 32 + g * 8 + half * 4;
+                int o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = min(max((int)__builtin_rint((double)acc[g * 4 + e] * sC1[n0 + e]), -128), 127);
+                    mx = max(mx, o[e]);
+                }
+                unsigned w01 = __builtin_amdgcn_perm((unsigned)o[1], (unsigned)o[0], 0x0c0c0400u);
+                unsigned w23 = __builtin_amdgcn_perm((unsigned)o[3], (unsigned)o[2], 0x0c0c0400u);
+                // hidden channel n0..n0+3 of token (mt*32 + l31): fc2 B-fragment layout [k/32][token][32 B]
+                *reinterpret_cast<unsigned *>(sm + MF_H + nt * (MF_BM * 32) + (mt * 32 + l31) * 32 + g * 8 + half * 4) =
+                    __builtin_amdgcn_perm(w23, w01, 0x05040100u);
+            }
+            atomicMax(&sMax[mt * 32 + l31], mx);
+        }
+        __syncthreads();
+        // ---- S2: the table row of each token's max -> LDS (64 rows x 256 B = 1024 chunks of 16 B)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ch = tid + i * 512, t = ch >> 4, c16 = ch & 15;
+            *reinterpret_cast<v4i *>(sm + MF_ROWS + t * 256 + c16 * 16) =
+                *reinterpret_cast<const v4i *>(p.tab + (sMax[t] + 128) * 256 + c16 * 16);
+        }
+        __syncthreads();
+        // ---- S3: ShiftGELU(+requant) by table, in place: 24576 bytes = 6144 dwords, 12 per thread
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const int dw = tid + i * 512;                          // dword index in H: [kc][token][8 dwords]
+            const int t = (dw >> 3) & (MF_BM - 1);
+            const unsigned char *L = reinterpret_cast<const unsigned char *>(sm + MF_ROWS + t * 256);
+            unsigned *hp = reinterpret_cast<unsigned *>(sm + MF_H) + dw;
+            const unsigned w = *hp ^ 0x80808080u;
+            *hp = (unsigned)L[w & 0xff] | ((unsigned)L[(w >> 8) & 0xff] << 8) | ((unsigned)L[(w >> 16) & 0xff] << 16) |
+                  ((unsigned)L[w >> 24] << 24);
+        }
+        __syncthreads();
+        // ---- S4: fc2 on waves 0..5: sub-tile (nt2, mt), K = 384
+        if (wave < 6) {
+            const int nt = wave >> 1, mt = wave & 1;
+            v16i_sw acc;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const v4i b4 = *reinterpret_cast<const v4i *>(sB2 + nt * 32 + g * 8 + half * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[g * 4 + e] = b4[e];
+            }
+#pragma unroll
+            for (int kc = 0; kc < 12; ++kc) {
+                const v4i wf = *reinterpret_cast<const v4i *>(sm + MF_W2 + kc * (MF_C * 32) + (nt * 32 + l31) * 32 + half * 16);
+                const v4i gf = *reinterpret_cast<const v4i *>(sm + MF_H + kc * (MF_BM * 32) + (mt * 32 + l31) * 32 + half * 16);
+                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf, gf, acc, 0, 0, 0);
+            }
+            // C^T[n][token]: lane = token, quad g -> channels nt*32 + 8g + 4*half + (0..3); 16-bit requant, pack
+            unsigned W[4][2];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n0 = nt * 32 + g * 8 + half * 4;
+                int o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    o[e] = min(max((int)__builtin_rint((double)acc[g * 4 + e] * sC2[n0 + e]), -32768), 32767);
+                W[g][0] = __builtin_amdgcn_perm((unsigned)o[1], (unsigned)o[0], 0x05040100u);
+                W[g][1] = __builtin_amdgcn_perm((unsigned)o[3], (unsigned)o[2], 0x05040100u);
+            }
+            const long long tok = tile * MF_BM + mt * 32 + l31;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {                          // after the exchange: 8 channels per (q, half)
+                auto x0 = __builtin_amdgcn_permlane32_swap(W[q][0], W[q + 2][0], false, false);
+                auto x1 = __builtin_amdgcn_permlane32_swap(W[q][1], W[q + 2][1], false, false);
+                v4i v = {(int)x0[0], (int)x1[0], (int)x0[1], (int)x1[1]};
+                const int ch0 = nt * 32 + half * 16 + q * 8;
+                if (tok < p.M) {
+                    const long long off = tok * MF_C + ch0;
+                    const v4i rs = *reinterpret_cast<const v4i *>(p.residual + off);
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const int t0 = (int)(short)(v[w] & 0xffff), t1 = v[w] >> 16;
+                        const int r0 = (int)(short)(rs[w] & 0xffff), r1 = rs[w] >> 16;
+                        int o0 = (int)__builtin_rint((double)r0 * cr) + (int)__builtin_rint((double)t0 * cm);
+                        int o1 = (int)__builtin_rint((double)r1 * cr) + (int)__builtin_rint((double)t1 * cm);
+                        o0 = min(max(o0, -32768), 32767);
+                        o1 = min(max(o1, -32768), 32767);
+                        v[w] = (o0 & 0xffff) | (o1 << 16);
+                    }
+                    *reinterpret_cast<v4i *>(p.out + off) = v;
+                }
+            }
+        }
+    }
+}

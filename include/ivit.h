@@ -324,6 +324,15 @@ int ivit_layernorm_tokenorder_requant(ivit_handle h, const int16_t *x, int64_t r
 int ivit_window_attention_fused(ivit_handle h, const int8_t *qkv, ivit_dyadic dy_qk, ivit_dyadic dy_a,
                                 const int16_t *relb, float s_softmax, ivit_dyadic dy_pv, int8_t *ctx,
                                 int B, int R, int window, int shift, int heads, int dh);
+/* Fused Mlp.forward + closing QuantAct(identity) for a narrow stage (layers_quant.py:144-153,
+ * swin_quant.py:293-296): fc1 -> qact_gelu(8) -> ShiftGELU -> qact1(8) -> fc2 -> qact2(16) -> qact4(16, +identity)
+ * with both weight matrices resident in LDS and the hidden tensor never written to HBM.
+ * x int8 [M, C] (norm2 -> qact3), gelu_table from ivit_shiftgelu_build_table, residual / out int16 [M, C].
+ * Built for C = 96, hidden = 384 (Swin-T/S stage 0); other shapes: IVIT_ERR_UNSUPPORTED.               */
+int ivit_mlp_fused(ivit_handle h, const int8_t *x, const int8_t *w1, const int32_t *b1, const ivit_dyadic *dy1,
+                   const int8_t *gelu_table, const int8_t *w2, const int32_t *b2, const ivit_dyadic *dy2,
+                   ivit_dyadic dy_main, ivit_dyadic dy_res, const int16_t *residual, int16_t *out, int64_t M,
+                   int C, int hidden);
 /* PatchMerging's 2x2 gather (swin_quant.py:336-342): x [B,R,R,C] (in_bits 8 or 16) ->
  * int16 [B, (R/2)^2, 4C], channel blocks in the reference's torch.cat order.                  */
 int ivit_patch_merge_gather(ivit_handle h, const void *x, int in_bits, int B, int R, int C, int16_t *out);

@@ -647,3 +647,31 @@ def test_act_out_int8_logits_extension():
     assert np.array_equal(q8.cpu().numpy().astype(np.int32), ref)
     assert np.array_equal(q8b.cpu().numpy(), q8.cpu().numpy()) and q8.dtype == torch.int8
     assert np.abs(q8.cpu().numpy().astype(np.int32)).max() == 127       # the calibrated range is used in full
+
+
+@pytest.mark.parametrize("M", [64, 1000, 64 * 300 + 17])
+def test_mlp_fused_equals_unfused_chain(H, M):
+    """ivit_mlp_fused (weights resident in LDS, hidden never in HBM) == fc1+requant -> GELU table -> fc2+requant
+    +identity issued as three kernels; ragged last tile included."""
+    rng = np.random.default_rng(M)
+    C, HD = 96, 384
+    x = dev(rng.integers(-128, 128, (M, C), dtype=np.int8))
+    w1 = dev(rng.integers(-128, 128, (HD, C), dtype=np.int8)); b1 = dev(rng.integers(-3000, 3000, HD).astype(np.int32))
+    w2 = dev(rng.integers(-128, 128, (C, HD), dtype=np.int8)); b2 = dev(rng.integers(-3000, 3000, C).astype(np.int32))
+    d1 = dev(iv.freeze.dyadic((10 ** rng.uniform(-5.3, -4.9, HD)).astype(np.float32), np.float32(0.012)))
+    d2 = dev(iv.freeze.dyadic((10 ** rng.uniform(-5.6, -5.2, C)).astype(np.float32), np.float32(2e-4)))
+    dm = iv.freeze.dyadic(np.float32(2e-4), np.float32(3.1e-4)); dr = iv.freeze.dyadic(np.float32(2.7e-4), np.float32(3.1e-4))
+    res = dev(rng.integers(-30000, 30000, (M, C)).astype(np.int16))
+    tab = torch.empty(65536, dtype=torch.int8, device="cuda")
+    H.call("ivit_shiftgelu_build_table", 0.03, dyv(iv.freeze.dyadic(np.float32(0.03 * 2.0 ** -7), np.float32(0.02))), P(tab))
+    h8 = torch.empty(M, HD, dtype=torch.int8, device="cuda"); g8 = torch.empty_like(h8)
+    ref = torch.empty(M, C, dtype=torch.int16, device="cuda"); out = torch.full((M, C), -7, dtype=torch.int16, device="cuda")
+    H.call("ivit_linear_i8_requant", P(x), P(w1), P(b1), P(d1), 8, P(h8), M, HD, C)
+    H.call("ivit_shiftgelu_requant_lut", P(h8), M, HD, P(tab), P(g8))
+    H.call("ivit_linear_i8_requant_residual", P(g8), P(w2), P(b2), P(d2), dyv(dm), dyv(dr), P(res), P(ref), M, C, HD)
+    H.call("ivit_mlp_fused", P(x), P(w1), P(b1), P(d1), P(tab), P(w2), P(b2), P(d2), dyv(dm), dyv(dr), P(res), P(out), M, C, HD)
+    assert np.abs(h8.cpu().numpy().astype(np.int32)).max() >= 127          # the hidden tensor saturates in places
+    assert np.array_equal(out.cpu().numpy(), ref.cpu().numpy())
+    # unsupported shapes say so instead of running something else
+    st = H.lib.ivit_mlp_fused(H.h, P(x), P(w1), P(b1), P(d1), P(tab), P(w2), P(b2), P(d2), dyv(dm), dyv(dr), P(res), P(out), M, 192, 768)
+    assert st == 3
