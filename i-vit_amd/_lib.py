@@ -126,6 +126,7 @@ SIGNATURES = {
     "ivit_quantize_input_f32": [_P, _P, _F, _P, _L],
     "ivit_requant_i16": [_P, _P, _P, _I, _P, _P, _I, _P, _L, _I],
     "ivit_layernorm_tokenorder_requant": [_P, _P, _L, _I, _F, _P, _P, _P, _I, _P],
+    "ivit_patch_norm_tokenorder": [_P, _P, _L, _I, _F, _P, _P, _P, Dyadic, _I, _P],
     "ivit_window_attention_fused": [_P, _P, Dyadic, Dyadic, _P, _F, Dyadic, _P, _I, _I, _I, _I, _I, _I],
     "ivit_mlp_fused": [_P, _P, _P, _P, _P, _P, _P, _P, _P, Dyadic, Dyadic, _P, _P, _L, _I, _I],
     "ivit_patch_merge_gather": [_P, _P, _I, _I, _I, _I, _P],

@@ -499,13 +499,34 @@ int ivit_layernorm_tokenorder_requant(ivit_handle h, const int16_t *x, int64_t r
     const size_t lds = ((size_t)LNT_ROWS * (C + 1) + 3 * (size_t)C + 2 * LNT_ROWS + 2) * sizeof(float) + (size_t)C * sizeof(double);
     REQUIRE(h, lds <= 160 * 1024, "C too large for LDS staging");
     if (C == 96) {          // Swin-T/S stage 0
-        layernorm_tokenorder_kernel<true, 96><<<(unsigned)((rows + LNT_ROWS - 1) / LNT_ROWS), 256, lds, h->stream>>>(
+        layernorm_tokenorder_kernel<1, 96><<<(unsigned)((rows + LNT_ROWS - 1) / LNT_ROWS), 256, lds, h->stream>>>(
             x, rows, C, scale, bias_int, sc, dy, tokens_per_image, out8);
     } else {
-        int st = set_dyn_lds(h, (const void *)layernorm_tokenorder_kernel<true, 0>, lds);
+        int st = set_dyn_lds(h, (const void *)layernorm_tokenorder_kernel<1, 0>, lds);
         if (st) return st;
-        layernorm_tokenorder_kernel<true, 0><<<(unsigned)((rows + LNT_ROWS - 1) / LNT_ROWS), 256, lds, h->stream>>>(
+        layernorm_tokenorder_kernel<1, 0><<<(unsigned)((rows + LNT_ROWS - 1) / LNT_ROWS), 256, lds, h->stream>>>(
             x, rows, C, scale, bias_int, sc, dy, tokens_per_image, out8);
+    }
+    LAUNCH_CHECK(h);
+    return IVIT_OK;
+}
+
+int ivit_patch_norm_tokenorder(ivit_handle h, const int8_t *x8, int64_t rows, int C, float scale, const float *bias_int,
+                               const float *sc, const ivit_dyadic *dy_ch, ivit_dyadic dy2, int tokens_per_image,
+                               int16_t *out16) {
+    CHECK_H(h);
+    REQUIRE(h, x8 && bias_int && sc && dy_ch && out16 && rows > 0 && C > 0 && scale > 0.f && tokens_per_image > 0, "bad arguments");
+    const size_t lds = ((size_t)LNT_ROWS * (C + 1) + 3 * (size_t)C + 2 * LNT_ROWS + 2) * sizeof(float) + (size_t)C * sizeof(double);
+    REQUIRE(h, lds <= 160 * 1024, "C too large for LDS staging");
+    const unsigned grid = (unsigned)((rows + LNT_ROWS - 1) / LNT_ROWS);
+    if (C == 96) {
+        layernorm_tokenorder_kernel<2, 96, int8_t><<<grid, 256, lds, h->stream>>>(x8, rows, C, scale, bias_int, sc, dy_ch,
+                                                                            tokens_per_image, out16, dy2);
+    } else {
+        int st = set_dyn_lds(h, (const void *)layernorm_tokenorder_kernel<2, 0, int8_t>, lds);
+        if (st) return st;
+        layernorm_tokenorder_kernel<2, 0, int8_t><<<grid, 256, lds, h->stream>>>(x8, rows, C, scale, bias_int, sc, dy_ch,
+                                                                           tokens_per_image, out16, dy2);
     }
     LAUNCH_CHECK(h);
     return IVIT_OK;
@@ -517,9 +538,9 @@ int ivit_layernorm_tokenorder(ivit_handle h, const int16_t *x, int64_t rows, int
     REQUIRE(h, x && bias_int && sc && z && rows > 0 && C > 0 && scale > 0.f && tokens_per_image > 0, "bad arguments");
     const size_t lds = ((size_t)LNT_ROWS * (C + 1) + 3 * (size_t)C + 2 * LNT_ROWS + 2) * sizeof(float) + (size_t)C * sizeof(double);
     REQUIRE(h, lds <= 160 * 1024, "C too large for LDS staging");
-    int st = set_dyn_lds(h, (const void *)layernorm_tokenorder_kernel<false, 0>, lds);
+    int st = set_dyn_lds(h, (const void *)layernorm_tokenorder_kernel<0, 0>, lds);
     if (st) return st;
-    layernorm_tokenorder_kernel<false, 0><<<(unsigned)((rows + LNT_ROWS - 1) / LNT_ROWS), 256, lds, h->stream>>>(
+    layernorm_tokenorder_kernel<0, 0><<<(unsigned)((rows + LNT_ROWS - 1) / LNT_ROWS), 256, lds, h->stream>>>(
         x, rows, C, scale, bias_int, sc, nullptr, tokens_per_image, z);
     LAUNCH_CHECK(h);
     return IVIT_OK;

@@ -281,6 +281,7 @@ struct ivit_swin_s {
     std::vector<ivit_swin_block> blocks;
     std::vector<ivit_swin_merge> merges;
     int grid, nblocks;
+    ivit_dyadic dy_qact1_host;        // host copy of prm.dy_qact1[0]
     bool fused_mlp;                   // IVIT_SWIN_FUSED_MLP=0 disables the stage-0 fused MLP (A/B, tests)
     int8_t *gelu_tab;                 // [nblocks][65536]
     int max_slices;
@@ -339,10 +340,7 @@ int swin_run_slice(const ivit_swin_s *m, ivit_handle h, const int8_t *images, in
     // PatchEmbed: conv -> qact_before_norm(8) -> norm (token-order sums) -> qact(16) -> qact1(16)
     RUN(ivit_im2col_patch(h, images, B, c.in_chans, c.img_size, c.img_size, c.patch_size, patches));
     RUN(ivit_linear_i8_requant(h, patches, P.pe.w, P.pe.b, P.pe.dy, 8, a8, (int)M, E, Kp));
-    RUN(ivit_widen_i8_i16(h, a8, y, M * E));
-    RUN(ivit_layernorm_tokenorder(h, y, M, E, P.s_bn, P.pn.bias_int, P.pn.sc, L, zf));
-    RUN(ivit_requant_f32(h, zf, P.pn.dy, E, nullptr, nullptr, 16, y, M, E));
-    RUN(ivit_requant_i16(h, y, P.dy_qact1, 1, nullptr, nullptr, 16, x, M, E));
+    RUN(ivit_patch_norm_tokenorder(h, a8, M, E, P.s_bn, P.pn.bias_int, P.pn.sc, P.pn.dy, m->dy_qact1_host, L, x));
     int bi = 0;
     for (int li = 0; li < c.num_layers; ++li) {
         const int C = E << li, heads = c.num_heads[li];
@@ -403,7 +401,7 @@ int ivit_swin_destroy(ivit_swin m) {
 int ivit_swin_create(ivit_handle h, const ivit_swin_config *cfg, const ivit_swin_params *params, int max_slices,
                      ivit_swin *out) {
     CHECK_H(h);
-    REQUIRE(h, cfg && params && out && params->blocks_host, "null argument");
+    REQUIRE(h, cfg && params && out && params->blocks_host && params->dy_qact1, "null argument");
     REQUIRE(h, cfg->num_layers >= 1 && cfg->num_layers <= 4 && cfg->embed_dim > 0 && cfg->patch_size > 0 &&
                    cfg->img_size % cfg->patch_size == 0 && cfg->mlp_ratio > 0 && cfg->num_classes > 0,
             "bad model configuration");
@@ -426,6 +424,11 @@ int ivit_swin_create(ivit_handle h, const ivit_swin_config *cfg, const ivit_swin
     if (cfg->num_layers > 1) m->merges.assign(params->merges_host, params->merges_host + cfg->num_layers - 1);
     m->grid = grid; m->nblocks = nb; m->gelu_tab = nullptr; m->max_slices = max_slices; m->fork = nullptr;
     { const char *e = getenv("IVIT_SWIN_FUSED_MLP"); m->fused_mlp = e ? atoi(e) != 0 : true; }
+    if (hipMemcpy(&m->dy_qact1_host, params->dy_qact1, sizeof(ivit_dyadic), hipMemcpyDeviceToHost) != hipSuccess) {
+        snprintf(h->err, sizeof(h->err), "ivit_swin_create: cannot read dy_qact1");
+        delete m;
+        return IVIT_ERR_HIP;
+    }
     if (hipMalloc((void **)&m->gelu_tab, (size_t)nb * 65536) != hipSuccess) {
         snprintf(h->err, sizeof(h->err), "ivit_swin_create: hipMalloc failed");
         delete m;

@@ -124,12 +124,17 @@ __device__ __forceinline__ float strided_order_sum(const float *x, int n, bool i
 // are spread over all threads; only the two order-sensitive sums and the integer square root of a token run
 // on one thread (the first LNT_ROWS threads, one token each).  Per-channel divisors use the hoisted reciprocal (lean_div).
 #define LNT_ROWS 32
-template <bool OUT8, int CC>   // CC: compile-time channel count (index arithmetic by constants), 0 = run-time
-__global__ __launch_bounds__(256) void layernorm_tokenorder_kernel(const int16_t *__restrict__ x, long long rows, int C_rt,
+// OUTM: 0 = fp32 z, 1 = int8 (per-channel QuantAct), 2 = int16 after TWO QuantActs (per-channel 16 bit, then the
+// per-tensor dy2: PatchEmbed's norm -> qact(16) -> qact1(16), layers_quant.py:193-195 + swin_quant.py:543).
+// XT: element type of x (int16, or int8 straight from the 8-bit QuantAct before the norm).
+// CC: compile-time channel count (index arithmetic by constants), 0 = run-time.
+template <int OUTM, int CC, typename XT = int16_t>
+__global__ __launch_bounds__(256) void layernorm_tokenorder_kernel(const XT *__restrict__ x, long long rows, int C_rt,
                                                                    float s, const float *__restrict__ bias_int,
                                                                    const float *__restrict__ sc,
                                                                    const ivit_dyadic *__restrict__ dy, int L,
-                                                                   void *__restrict__ out) {
+                                                                   void *__restrict__ out, ivit_dyadic dy2 = ivit_dyadic{0.0, 0.0}) {
+    constexpr bool OUT8 = (OUTM == 1);
     const int C = CC ? CC : C_rt;
     extern __shared__ __attribute__((aligned(16))) char dsmem[];
     const int LD = C + 1;
@@ -145,8 +150,9 @@ __global__ __launch_bounds__(256) void layernorm_tokenorder_kernel(const int16_t
         cSc[c] = scv;
         cY[c] = rcp_prepare(scv).y;
         cB[c] = bias_int[c];
-        if (OUT8) cC[c] = dy[c].m * dy[c].r;
+        if (OUTM != 0) cC[c] = dy[c].m * dy[c].r;
     }
+    const double c2 = dy2.m * dy2.r;
     const int total = LNT_ROWS * C;
     for (int e = tid; e < total; e += 256) {
         const int r = e / C, c = e - r * C;
@@ -186,8 +192,14 @@ __global__ __launch_bounds__(256) void layernorm_tokenorder_kernel(const int16_t
         rc.d = cSc[c];
         rc.y = cY[c];
         const float zv = rintf(lean_div(o * rc.d, rc));
-        if (OUT8) reinterpret_cast<int8_t *>(out)[gr * C + c] = (int8_t)rq_c((double)zv, cC[c], -128, 127);
-        else reinterpret_cast<float *>(out)[gr * C + c] = zv;
+        if (OUT8) {
+            reinterpret_cast<int8_t *>(out)[gr * C + c] = (int8_t)rq_c((double)zv, cC[c], -128, 127);
+        } else if (OUTM == 2) {
+            const int v16 = rq_c((double)zv, cC[c], -32768, 32767);
+            reinterpret_cast<int16_t *>(out)[gr * C + c] = (int16_t)rq_c((double)v16, c2, -32768, 32767);
+        } else {
+            reinterpret_cast<float *>(out)[gr * C + c] = zv;
+        }
     }
 }
 

@@ -314,6 +314,11 @@ int ivit_layernorm_tokenorder(ivit_handle h, const int16_t *x, int64_t rows, int
 int ivit_layernorm_tokenorder_requant(ivit_handle h, const int16_t *x, int64_t rows, int C, float scale,
                                       const float *bias_int, const float *sc, const ivit_dyadic *dy,
                                       int tokens_per_image, int8_t *out8);
+/* PatchEmbed's tail in one pass (layers_quant.py:193-195, swin_quant.py:543): int8 conv output ->
+ * norm (token-order sums) -> qact (16 bit, per-channel dy_ch) -> qact1 (16 bit, per-tensor dy2).          */
+int ivit_patch_norm_tokenorder(ivit_handle h, const int8_t *x8, int64_t rows, int C, float scale,
+                               const float *bias_int, const float *sc, const ivit_dyadic *dy_ch,
+                               ivit_dyadic dy2, int tokens_per_image, int16_t *out16);
 /* Fused windowed attention: everything of WindowAttention.forward (swin_quant.py:121-169) between
  * the qkv QuantAct and proj — q.k^T*scale -> qact_attn1 -> (+ relative position bias) qact2 ->
  * Shiftmax 8 bit on attn (+ shift mask, :151-156) -> attn.v -> qact3 — including torch.roll,
