@@ -594,7 +594,8 @@ int ivit_window_attention_fused(ivit_handle h, const int8_t *qkv, ivit_dyadic dy
     a.qkv = qkv; a.ctx = ctx; a.relb = relb; a.B = B; a.R = R; a.shift = shift; a.heads = heads;
     a.dy_qk = dy_qk; a.dy_a = dy_a; a.dy_pv = dy_pv; a.s = s_softmax;
     a.units = (long long)B * (R / 7) * (R / 7) * heads;
-    window_attention_kernel<<<dim3((unsigned)((a.units + 3) / 4)), 256, 0, h->stream>>>(a);
+    const long long nwin = (long long)B * (R / 7) * (R / 7);
+    window_attention_kernel<<<dim3((unsigned)(((nwin + 3) / 4) * heads)), 256, 0, h->stream>>>(a);
     LAUNCH_CHECK(h);
     return IVIT_OK;
 }

@@ -228,14 +228,15 @@ struct WinAttnArgs {
     long long units;        // B * (R/7)^2 * heads
 };
 
-__global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs p) {
-    __shared__ __attribute__((aligned(16))) char sm[4 * (2048 + 4816 + 64) + 512 + 1024];
+__global__ __launch_bounds__(256, 4) void window_attention_kernel(WinAttnArgs p) {
+    // a block = ONE head x 4 windows: the head's relative-position slab is staged once for the four wavefronts
+    __shared__ __attribute__((aligned(16))) char sm[4 * (2048 + 64) + 4816 + 512 + 1024];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     char *sV = sm + wave * 2048;                                            // [64 keys][32 d]
-    int16_t *sRel = reinterpret_cast<int16_t *>(sm + 4 * 2048 + wave * 4816);   // [49][49]
-    unsigned char *sReg = reinterpret_cast<unsigned char *>(sm + 4 * (2048 + 4816) + wave * 64);
-    int16_t *sTa = reinterpret_cast<int16_t *>(sm + 4 * (2048 + 4816 + 64));    // rq(v, dy_a), v = -128..127
-    float *sTx = reinterpret_cast<float *>(sm + 4 * (2048 + 4816 + 64) + 512);  // fl(fl(a*s)/s)
+    unsigned char *sReg = reinterpret_cast<unsigned char *>(sm + 4 * 2048 + wave * 64);
+    int16_t *sRel = reinterpret_cast<int16_t *>(sm + 4 * (2048 + 64));          // [49][49], shared by the block
+    int16_t *sTa = reinterpret_cast<int16_t *>(sm + 4 * (2048 + 64) + 4816);    // rq(v, dy_a), v = -128..127
+    float *sTx = reinterpret_cast<float *>(sm + 4 * (2048 + 64) + 4816 + 512);  // fl(fl(a*s)/s)
     const float s = p.s;
     const RcpC sr = rcp_prepare(s);
     {
@@ -243,12 +244,21 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs p) {
         sTa[tid] = (int16_t)(int)__builtin_rint((double)(tid - 128) * ca);
         sTx[tid] = requotient_c((float)(tid - 128), sr);
     }
+    const int head = (int)(blockIdx.x % p.heads);
+    {
+        const unsigned *rb = reinterpret_cast<const unsigned *>(p.relb + (long long)head * 2401);   // 2401 int16: 1200 dwords + 1
+        const bool al = ((head * 2401) & 1) == 0;              // odd heads start on a 2-byte boundary
+        if (al) {
+            for (int i = tid; i < 1200; i += 256) reinterpret_cast<unsigned *>(sRel)[i] = rb[i];
+            if (tid == 0) sRel[2400] = p.relb[(long long)head * 2401 + 2400];
+        } else {
+            for (int i = tid; i < 2401; i += 256) sRel[i] = p.relb[(long long)head * 2401 + i];
+        }
+    }
     __syncthreads();
-    const long long unit = (long long)blockIdx.x * 4 + wave;
-    if (unit >= p.units) return;
     const int R = p.R, nw = R / 7, C = p.heads * 32;
-    const int head = (int)(unit % p.heads);
-    const long long wlin = unit / p.heads;
+    const long long wlin = (long long)(blockIdx.x / p.heads) * 4 + wave;
+    if (wlin >= (long long)p.B * nw * nw) return;
     const int win = (int)(wlin % (nw * nw)), b = (int)(wlin / (nw * nw));
     const int wi = win / nw, wj = win - wi * nw;
     auto tok_off = [&](int n) -> long long {                 // natural token index of window token n
@@ -279,10 +289,6 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs p) {
         v4i v = {0, 0, 0, 0};
         if (n < 49) v = *reinterpret_cast<const v4i *>(p.qkv + tok_off(n) * (3 * C) + 2 * C + head * 32 + hh * 16);
         *reinterpret_cast<v4i *>(sV + n * 32 + hh * 16) = v;
-    }
-    {
-        const int16_t *rb = p.relb + (long long)head * 2401;
-        for (int i = lane; i < 2401; i += 64) sRel[i] = rb[i];
     }
     if (lane < 49) {
         const int wy = lane / 7, wx = lane - wy * 7, ys = wi * 7 + wy, xs = wj * 7 + wx;
