@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void layernorm16_kernel(const int16_t *__restr
                                                           const float *__restrict__ bias_int,
                                                           const float *__restrict__ sc,
                                                           const ivit_dyadic *__restrict__ dy,
-                                                          int8_t *__restrict__ out) {
+                                                          int8_t *__restrict__ out, int riter) {
     const int C = CC ? CC : C_rt;
     extern __shared__ __attribute__((aligned(16))) char dsmem[];
     const int LD = C + 16;                                   // row stride (floats): skews rows by 16 banks
@@ -232,8 +232,8 @@ __global__ __launch_bounds__(256) void layernorm16_kernel(const int16_t *__restr
     const RcpC sr = rcp_prepare(s);
     const float Cf = (float)C;
     const int nch8 = C >> 3;
-    for (int it = 0; it < LN_RITER; ++it) {
-        const long long row_raw = ((long long)blockIdx.x * LN_RITER + it) * 16 + slot;
+    for (int it = 0; it < riter; ++it) {       // riter row groups per block: chosen by the host to fill the chip
+        const long long row_raw = ((long long)blockIdx.x * riter + it) * 16 + slot;
         const bool live = row_raw < rows;
         const long long row = live ? row_raw : rows - 1;     // dead groups recompute the last row, store nothing
         const int16_t *xp = x + row * row_stride;

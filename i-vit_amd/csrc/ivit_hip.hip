@@ -425,14 +425,19 @@ int ivit_layernorm_requant(ivit_handle h, const int16_t *x, int64_t rows, int C,
         static int ln_old = -1;
         if (ln_old < 0) { const char *e = getenv("IVIT_LN_OLD"); ln_old = e ? atoi(e) : 0; }
         if (lds16 <= 150 * 1024 && !ln_old) {
-            const long long per_block = 16 * LN_RITER;
+            // row groups per block: up to LN_RITER (amortises the constant staging), fewer when the launch would
+            // otherwise leave CUs idle (>= 3 blocks per CU wanted)
+            long long riter = rows / (16LL * 3 * h->num_cu);
+            riter = riter < 1 ? 1 : (riter > LN_RITER ? LN_RITER : riter);
+            { static int force = -1; if (force < 0) { const char *e = getenv("IVIT_LN_RITER"); force = e ? atoi(e) : 0; } if (force > 0) riter = force; }
+            const long long per_block = 16 * riter;
             const unsigned grid = (unsigned)((rows + per_block - 1) / per_block);
 #define LN16_LAUNCH(CC)                                                                                   \
             do {                                                                                          \
                 int st16 = set_dyn_lds(h, (const void *)layernorm16_kernel<CC>, lds16);                   \
                 if (st16) return st16;                                                                    \
                 layernorm16_kernel<CC><<<grid, 256, lds16, h->stream>>>(x, rows, C, row_stride, scale,    \
-                                                                       bias_int, sc, dy_ch, out8);       \
+                                                                       bias_int, sc, dy_ch, out8, (int)riter); \
             } while (0)
             if (C == 384) LN16_LAUNCH(384);          // DeiT-S / Swin stage 2
             else if (C == 768) LN16_LAUNCH(768);     // DeiT-B, ViT-B / Swin stage 3
