@@ -35,6 +35,39 @@ __global__ __launch_bounds__(256) void quantize_input_kernel(const float *__rest
 }
 
 // ---------------------------------------------------------------------------
+// N3 (part): ToTensor -> Normalize -> input QuantAct on the device (utils/data_utils.py:89-91, then a4):
+//   q = clamp(rne(fl(fl(1/s) * fl(fl(fl(u / 255) - mean[c]) / std[c]))), -128, 127)   for a uint8 pixel u.
+// Only 3 x 256 distinct inputs exist: every block rebuilds that table with the exact fp32 sequence (IEEE
+// divisions, -ffp-contract=off) and the image pass is a byte gather with the HWC -> CHW transpose.
+__global__ __launch_bounds__(256) void normalize_quantize_u8_kernel(const unsigned char *__restrict__ u, int B, int H, int W,
+                                                                    float m0, float m1, float m2, float s0, float s1,
+                                                                    float s2, float scale, int8_t *__restrict__ q) {
+    __shared__ signed char lut[3][256];
+    const int tid = threadIdx.x;
+    const float inv = 1.0f / scale;
+    for (int i = tid; i < 768; i += 256) {
+        const int c = i >> 8, uv = i & 255;
+        const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+        float v = (float)uv / 255.0f;
+        v = v - mean;
+        v = v / sd;
+        float r = rintf(inv * v);
+        r = fminf(fmaxf(r, -128.f), 127.f);
+        lut[c][uv] = (signed char)(int)r;
+    }
+    __syncthreads();
+    const long long HW = (long long)H * W, total = (long long)B * HW;      // one thread per pixel (3 bytes in, 3 out)
+    for (long long i = (long long)blockIdx.x * 256 + tid; i < total; i += (long long)gridDim.x * 256) {
+        const long long b = i / HW, p = i - b * HW;
+        const unsigned char *src = u + i * 3;
+        int8_t *dst = q + b * 3 * HW + p;
+        dst[0] = lut[0][src[0]];
+        dst[HW] = lut[1][src[1]];
+        dst[2 * HW] = lut[2][src[2]];
+    }
+}
+
+// ---------------------------------------------------------------------------
 // a3: generic dyadic requant (quant_utils.py:213-253); one thread per element group
 template <typename ZT, int BITS>
 __global__ __launch_bounds__(256) void requant_kernel(const ZT *__restrict__ z, const ivit_dyadic *__restrict__ dy,

@@ -83,6 +83,17 @@ int ivit_quantize_input_f32(ivit_handle h, const float *x, float scale, int8_t *
     return IVIT_OK;
 }
 
+int ivit_normalize_quantize_u8(ivit_handle h, const uint8_t *hwc, int B, int H, int W, const float mean[3],
+                               const float std_[3], float scale, int8_t *nchw) {
+    CHECK_H(h);
+    REQUIRE(h, hwc && nchw && mean && std_ && B > 0 && H > 0 && W > 0 && scale > 0.f, "bad arguments");
+    REQUIRE(h, std_[0] != 0.f && std_[1] != 0.f && std_[2] != 0.f, "zero std");
+    normalize_quantize_u8_kernel<<<grid_for(h, (long long)B * H * W, 256), 256, 0, h->stream>>>(
+        hwc, B, H, W, mean[0], mean[1], mean[2], std_[0], std_[1], std_[2], scale, nchw);
+    LAUNCH_CHECK(h);
+    return IVIT_OK;
+}
+
 }  // extern "C"
 
 // ---------------------------------------------------------------- GEMM launchers

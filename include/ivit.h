@@ -60,6 +60,12 @@ const char *ivit_last_error(ivit_handle h);
 /* ---- a4  QuantAct.forward, input branch  (quant_modules.py:194-196 ->
  * quant_utils.py:77-96, 12-48):  q = clamp(rne(fl(fl(1/s)*x)), -128, 127)            */
 int ivit_quantize_input_f32(ivit_handle h, const float *x, float scale, int8_t *q, int64_t n);
+/* ToTensor -> Normalize(mean, std) -> the same input QuantAct, from uint8 pixels on the device
+ * (utils/data_utils.py:89-91: transforms.ToTensor, transforms.Normalize; then vit_quant.py:257):
+ * hwc uint8 [B, H, W, 3] (a centre-cropped image as PIL hands it over) -> nchw int8 [B, 3, H, W].
+ * mean / std are HOST arrays of 3 floats.  Resize / crop stay on the host.       */
+int ivit_normalize_quantize_u8(ivit_handle h, const uint8_t *hwc, int B, int H, int W, const float mean_host[3],
+                               const float std_host[3], float scale, int8_t *nchw);
 
 /* ---- a1  QuantLinear.forward  (quant_modules.py:67-97) — integer accumulators.
  * acc[i,j] = sum_k x[i,k]*w[j,k] + bias[j];  x int8 [M,K], w int8 [N,K], K % 16 == 0. */

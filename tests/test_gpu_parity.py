@@ -675,3 +675,21 @@ def test_mlp_fused_equals_unfused_chain(H, M):
     # unsupported shapes say so instead of running something else
     st = H.lib.ivit_mlp_fused(H.h, P(x), P(w1), P(b1), P(d1), P(tab), P(w2), P(b2), P(d2), dyv(dm), dyv(dr), P(res), P(out), M, 192, 768)
     assert st == 3
+
+
+def test_normalize_quantize_u8_matches_torch_transform_chain():
+    """N3 (device part): uint8 HWC -> ToTensor -> Normalize -> input QuantAct == the same chain in torch CPU
+    fp32 (what torchvision's ToTensor / Normalize compute), for every pixel value and odd image sizes."""
+    from ivit_amd.preprocess import normalize_quantize, IMAGENET_DEFAULT_MEAN as MEAN, IMAGENET_DEFAULT_STD as STD
+    rng = np.random.default_rng(3)
+    for (B, Hh, W), scale in (((2, 16, 16), 0.0207), ((3, 37, 53), 0.0181), ((1, 224, 224), 0.02078)):
+        u = rng.integers(0, 256, (B, Hh, W, 3), dtype=np.uint8)
+        u.reshape(-1)[:256] = np.arange(256, dtype=np.uint8)
+        t = torch.from_numpy(u).permute(0, 3, 1, 2).float().div(255)                       # ToTensor
+        mean = torch.tensor(MEAN, dtype=torch.float32).view(1, 3, 1, 1)
+        std = torch.tensor(STD, dtype=torch.float32).view(1, 3, 1, 1)
+        x = t.sub(mean).div(std)                                                           # Normalize
+        inv = np.float32(1.0) / np.float32(scale)
+        ref = torch.clamp(torch.round(x * float(inv)), -128, 127).to(torch.int8).numpy()    # quant_utils.py:12-48
+        got = normalize_quantize(dev(u), scale).cpu().numpy()
+        assert np.array_equal(got, ref), (B, Hh, W)
