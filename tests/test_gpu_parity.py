@@ -693,3 +693,31 @@ def test_normalize_quantize_u8_matches_torch_transform_chain():
         ref = torch.clamp(torch.round(x * float(inv)), -128, 127).to(torch.int8).numpy()    # quant_utils.py:12-48
         got = normalize_quantize(dev(u), scale).cpu().numpy()
         assert np.array_equal(got, ref), (B, Hh, W)
+
+
+@pytest.mark.parametrize("spec", [("r0", 48, 16, 64, 1, 1, 10, 3), ("r1", 32, 8, 128, 2, 2, 7, 5), ("r2", 64, 16, 192, 1, 3, 33, 2),
+                                  ("r3", 32, 16, 64, 2, 2, 5, 9)])
+def test_random_shapes_self_calibrated_engine_vs_oracle(spec):
+    """shapes no fixture covers (token counts 5..17, 1..3 heads, head dim 32 -> unfused attention path, odd class
+    counts, ragged batches): calibrate on the device, then the native runner (1 and 3 slices) must equal the CPU
+    oracle run on the same weights and the calibrated scales."""
+    from oracle import oracle as orc
+    name, img, patch, D, depth, heads, ncls, B = spec
+    cfg = iv.ViTConfig(name, img_size=img, patch_size=patch, num_classes=ncls, embed_dim=D, depth=depth, num_heads=heads)
+    w = iv.make_vit_weights(cfg, seed=len(name) + D)
+    m = iv.VisionTransformer(img_size=img, patch_size=patch, num_classes=ncls, embed_dim=D, depth=depth, num_heads=heads,
+                             mlp_ratio=4)
+    m.load_float_weights(w)
+    with torch.no_grad():
+        m(dev(iv.make_calibration_batch(cfg, 3, seed=17)))
+    iv.freeze_model(m)
+    scales = {k: v for k, v in m.act_scales().items() if v > 0}
+    imgs = iv.make_images_int8(cfg, B, seed=4)
+    ref, _ = orc.OracleViT(cfg, w, scales).forward(imgs)
+    eng = m.compile()
+    assert np.array_equal(eng.forward(dev(imgs)).cpu().numpy(), ref)
+    if B >= 3:
+        assert np.array_equal(eng.forward(dev(imgs), nslices=3).cpu().numpy(), ref)
+    with torch.no_grad():
+        acc, _ = m(dev(imgs))
+    assert np.array_equal(acc.cpu().numpy(), ref)
