@@ -49,6 +49,8 @@ class VitBlock(ctypes.Structure):
         ("s_ln1", ctypes.c_float), ("n1_bias_int", ctypes.c_void_p), ("n1_sc", ctypes.c_void_p), ("n1_dy", ctypes.c_void_p),
         ("qkv_w", ctypes.c_void_p), ("qkv_b", ctypes.c_void_p), ("qkv_dy", ctypes.c_void_p),
         ("dy_qk", Dyadic), ("s_softmax", ctypes.c_float), ("dy_pv", Dyadic),
+        ("exp_aq", ctypes.c_void_p), ("exp_t", ctypes.c_void_p), ("exp_cls", ctypes.c_void_p),
+        ("exp_nc", ctypes.c_int), ("exp_tcount", ctypes.c_int), ("exp_dmin", ctypes.c_int),
         ("proj_w", ctypes.c_void_p), ("proj_b", ctypes.c_void_p), ("proj_dy", ctypes.c_void_p),
         ("res1_main", Dyadic), ("res1_res", Dyadic),
         ("s_ln2", ctypes.c_float), ("n2_bias_int", ctypes.c_void_p), ("n2_sc", ctypes.c_void_p), ("n2_dy", ctypes.c_void_p),
@@ -154,6 +156,7 @@ SIGNATURES = {
     "ivit_attn_qk_requant": [_P, _P, _P, Dyadic, _P, _I, _I, _I, _I],
     "ivit_attn_pv_requant": [_P, _P, _P, Dyadic, _P, _I, _I, _I, _I, _I, _I],
     "ivit_attention_fused": [_P, _P, _P, _P, Dyadic, _F, Dyadic, _P, _I, _I, _I, _I, _I],
+    "ivit_attention_fused_lut": [_P, _P, _P, _P, Dyadic, _F, _P, _P, _P, _I, _I, _I, Dyadic, _P, _I, _I, _I, _I, _I],
     "ivit_requant_i32": [_P, _P, _P, _I, _P, _P, _I, _P, _L, _I],
     "ivit_requant_f32": [_P, _P, _P, _I, _P, _P, _I, _P, _L, _I],
     "ivit_shiftmax": [_P, _P, _L, _I, _I, _F, _I, _P, _I],

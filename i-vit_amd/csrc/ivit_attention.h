@@ -23,6 +23,11 @@ struct AttnArgs {
     int T, H, ldv;
     float s_softmax;           // scale of the int8 scores (qact_attn1)
     ivit_dyadic dy_qk, dy_pv;
+    // optional Shiftmax tables (ivit_amd.freeze.shiftmax_tables): exp_int = et[aq[class(vmax)][v] + max(v - vmax, dmin) - dmin]
+    const uint16_t *aq;        // [nc][256]
+    const float *et;           // [t_count]
+    const uint8_t *cls;        // [256] class of v
+    int nc, t_count, dmin;
 };
 
 #define ATT_WAVES 7
@@ -48,7 +53,9 @@ struct AttCfg {
 // FAST: |c_qk|, |c_pv| < 2^9 (host-checked) -> rq_fast is exact.  TT: the token count when it is known at
 // compile time (197 / 577: the 224- and 384-pixel ViTs), 0 = run-time p.T.  With TT fixed every tile-validity
 // test folds away; the generic form keeps ~70 loop-invariant lane masks alive and spills SGPRs in the hot loop.
-template <int NB, bool FAST, int TT = 0>
+// LUT: shift-exp by table lookup (two LDS gathers per score instead of ~20 fp32 operations); the tables follow
+// the fixed LDS regions and are copied in once per workgroup.
+template <int NB, bool FAST, int TT = 0, bool LUT = false>
 __global__ __launch_bounds__(ATT_WAVES * 64) void attn_fused_kernel(AttnArgs p) {
     using C = AttCfg<NB>;
     extern __shared__ __attribute__((aligned(16))) char dsmem[];
@@ -57,6 +64,9 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void attn_fused_kernel(AttnArgs p) 
     char *sO = sV + C::SV_BYTES;
     int *sCol = reinterpret_cast<int *>(sO + C::SO_BYTES);
     float *sXq = reinterpret_cast<float *>(sO + C::SO_BYTES + 256);   // fl(fl(Q*s)/s) for Q = -128..127
+    float *sT = reinterpret_cast<float *>(dsmem + C::SMEM);           // LUT only: exp table, then aq, then cls
+    unsigned short *sAQ = reinterpret_cast<unsigned short *>(sT + (LUT ? p.t_count : 0));
+    unsigned char *sCls = reinterpret_cast<unsigned char *>(sAQ + (LUT ? p.nc * 256 : 0));
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
@@ -94,6 +104,12 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void attn_fused_kernel(AttnArgs p) 
         for (int g = 0; g < 4; ++g) *reinterpret_cast<int *>(dst + g * 16) = v[g];
     }
     if (tid < 256) sXq[tid] = requotient_c((float)(tid - 128), rcp_prepare(p.s_softmax));
+    if (LUT) {
+        for (int i = tid; i < p.t_count; i += ATT_WAVES * 64) sT[i] = p.et[i];
+        for (int i = tid; i < p.nc * 128; i += ATT_WAVES * 64)
+            reinterpret_cast<unsigned *>(sAQ)[i] = reinterpret_cast<const unsigned *>(p.aq)[i];
+        if (tid < 64) reinterpret_cast<unsigned *>(sCls)[tid] = reinterpret_cast<const unsigned *>(p.cls)[tid];
+    }
     __syncthreads();
     if (tid < 64) {  // column sums of V (per d) over all keys
         int s = 0;
@@ -133,7 +149,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void attn_fused_kernel(AttnArgs p) 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     int v = FAST ? min(max(rq_fast(acc[r], c_qk), -128), 127) : rq_c((double)acc[r], c_qk, -128, 127);
-                    f[j][r] = sXq[v + 128];
+                    f[j][r] = LUT ? __int_as_float(v) : sXq[v + 128];      // LUT: the integer itself waits for vmax
                     if (j * 16 + 15 < T || j * 16 + g * 4 + r < T) qmax = max(qmax, v);
                 }
             } else {
@@ -144,15 +160,48 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void attn_fused_kernel(AttnArgs p) 
         qmax = max(qmax, __shfl_xor(qmax, 16));
         qmax = max(qmax, __shfl_xor(qmax, 32));
         const float mx = sXq[qmax + 128];
+        const int rowbase = LUT ? (int)sCls[qmax + 128] * 256 + 128 : 0;
 
         // ---- shift-exp; keys >= T contribute exactly 0
+        if (LUT) {
+            // two dependent LDS gathers per score, issued as two whole sweeps so the reads of a sweep are all in
+            // flight together (one wait per sweep instead of one per score)
+            const int qd = qmax + p.dmin;                       // max(v - vmax, dmin) - dmin == max(v - qd, 0)
 #pragma unroll
-        for (int j = 0; j < C::NT; ++j) {
-            if (j < ntile) {
+            for (int j0 = 0; j0 < C::NT; j0 += 4) {             // 16 scores per sweep: bounded extra registers
+                int e1[4][4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float e = shift_exp_nonpos(f[j][r] - mx, x0r, nx0, 15);
-                    f[j][r] = (j * 16 + 15 < T || j * 16 + g * 4 + r < T) ? e : 0.f;
+                for (int jj = 0; jj < 4; ++jj)
+                    if (j0 + jj < C::NT && j0 + jj < ntile) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) e1[jj][r] = (int)sAQ[rowbase + __float_as_int(f[j0 + jj][r])];
+                    }
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+                    if (j0 + jj < C::NT && j0 + jj < ntile) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) e1[jj][r] += max(__float_as_int(f[j0 + jj][r]) - qd, 0);
+                    }
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+                    if (j0 + jj < C::NT && j0 + jj < ntile) {
+                        const int j = j0 + jj;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float e = sT[e1[jj][r]];
+                            f[j][r] = (j * 16 + 15 < T || j * 16 + g * 4 + r < T) ? e : 0.f;
+                        }
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < C::NT; ++j) {
+                if (j < ntile) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float e = shift_exp_nonpos(f[j][r] - mx, x0r, nx0, 15);
+                        f[j][r] = (j * 16 + 15 < T || j * 16 + g * 4 + r < T) ? e : 0.f;
+                    }
                 }
             }
         }

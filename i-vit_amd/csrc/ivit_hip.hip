@@ -250,15 +250,15 @@ int ivit_attn_pv_requant(ivit_handle h, const uint16_t *p, const int8_t *vt, ivi
 
 }  // extern "C"
 
-template <int NB, bool FAST, int TT = 0>
+template <int NB, bool FAST, int TT = 0, bool LUT = false>
 static int launch_attn2(ivit_handle h, const AttnArgs &a, int BH) {
-    const size_t lds = AttCfg<NB>::SMEM;
+    const size_t lds = AttCfg<NB>::SMEM + (LUT ? (size_t)a.t_count * 4 + (size_t)a.nc * 512 + 256 : 0);
     if (lds > 65536) {
-        hipError_t e = hipFuncSetAttribute((const void *)attn_fused_kernel<NB, FAST, TT>,
+        hipError_t e = hipFuncSetAttribute((const void *)attn_fused_kernel<NB, FAST, TT, LUT>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { snprintf(h->err, sizeof(h->err), "attn attr: %s", hipGetErrorString(e)); return IVIT_ERR_HIP; }
     }
-    attn_fused_kernel<NB, FAST, TT><<<BH, ATT_WAVES * 64, lds, h->stream>>>(a);
+    attn_fused_kernel<NB, FAST, TT, LUT><<<BH, ATT_WAVES * 64, lds, h->stream>>>(a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(h->err, sizeof(h->err), "attn launch: %s", hipGetErrorString(e)); return IVIT_ERR_HIP; }
     return IVIT_OK;
@@ -268,18 +268,21 @@ template <int NB>
 static int launch_attn(ivit_handle h, const AttnArgs &a, int BH) {
     const double cq = a.dy_qk.m * a.dy_qk.r, cp = a.dy_pv.m * a.dy_pv.r;
     const bool fast = (cq < 512.0 && cq > -512.0 && cp < 512.0 && cp > -512.0);
-    static int dyn_t = -1;   // IVIT_ATTN_DYNAMIC_T=1: never use the fixed-T specialisations (A/B, tests)
+    static int dyn_t = -1, no_lut = -1;   // IVIT_ATTN_DYNAMIC_T=1 / IVIT_ATTN_NO_LUT=1: generic forms (A/B, tests)
     if (dyn_t < 0) { const char *e = getenv("IVIT_ATTN_DYNAMIC_T"); dyn_t = e ? atoi(e) : 0; }
+    if (no_lut < 0) { const char *e = getenv("IVIT_ATTN_NO_LUT"); no_lut = e ? atoi(e) : 0; }
+    const bool lut = a.aq && a.et && a.cls && !no_lut;
     if (fast && !dyn_t) {
-        if (NB == 4 && a.T == 197) return launch_attn2<NB, true, 197>(h, a, BH);
-        if (NB == 10 && a.T == 577) return launch_attn2<NB, true, 577>(h, a, BH);
+        if (NB == 4 && a.T == 197) return lut ? launch_attn2<NB, true, 197, true>(h, a, BH) : launch_attn2<NB, true, 197>(h, a, BH);
+        if (NB == 10 && a.T == 577) return lut ? launch_attn2<NB, true, 577, true>(h, a, BH) : launch_attn2<NB, true, 577>(h, a, BH);
     }
+    if (fast && lut) return launch_attn2<NB, true, 0, true>(h, a, BH);
     return fast ? launch_attn2<NB, true>(h, a, BH) : launch_attn2<NB, false>(h, a, BH);
 }
 
-extern "C" int ivit_attention_fused(ivit_handle h, const int8_t *q, const int8_t *k, const int8_t *vt,
-                                    ivit_dyadic dy_qk, float s_softmax, ivit_dyadic dy_pv, int8_t *ctx8, int B,
-                                    int H, int T, int dh, int ldv) {
+static int attention_fused_impl(ivit_handle h, const int8_t *q, const int8_t *k, const int8_t *vt, ivit_dyadic dy_qk,
+                                float s_softmax, ivit_dyadic dy_pv, int8_t *ctx8, int B, int H, int T, int dh, int ldv,
+                                const uint16_t *aq, const float *et, const uint8_t *cls, int nc, int t_count, int dmin) {
     CHECK_H(h);
     REQUIRE(h, q && k && vt && ctx8 && B > 0 && H > 0 && T > 0 && s_softmax > 0.f, "bad arguments");
     REQUIRE(h, (ldv % 16) == 0 && ldv >= T, "ldv must be a multiple of 16 and >= T");
@@ -287,12 +290,29 @@ extern "C" int ivit_attention_fused(ivit_handle h, const int8_t *q, const int8_t
         snprintf(h->err, sizeof(h->err), "ivit_attention_fused: built for dh == 64, T <= 640");
         return IVIT_ERR_UNSUPPORTED;
     }
+    if (aq) REQUIRE(h, et && cls && nc >= 1 && nc <= 64 && t_count >= 1 && t_count <= 16384 && dmin <= 0 && dmin >= -255,
+                    "bad Shiftmax tables");
     AttnArgs a;
     a.q = q; a.k = k; a.vt = vt; a.ctx = ctx8; a.T = T; a.H = H; a.ldv = ldv;
     a.s_softmax = s_softmax; a.dy_qk = dy_qk; a.dy_pv = dy_pv;
+    a.aq = aq; a.et = et; a.cls = cls; a.nc = nc; a.t_count = t_count; a.dmin = dmin;
     if (T <= 64) return launch_attn<1>(h, a, B * H);
     if (T <= 256) return launch_attn<4>(h, a, B * H);
     return launch_attn<10>(h, a, B * H);
+}
+
+extern "C" int ivit_attention_fused(ivit_handle h, const int8_t *q, const int8_t *k, const int8_t *vt,
+                                    ivit_dyadic dy_qk, float s_softmax, ivit_dyadic dy_pv, int8_t *ctx8, int B,
+                                    int H, int T, int dh, int ldv) {
+    return attention_fused_impl(h, q, k, vt, dy_qk, s_softmax, dy_pv, ctx8, B, H, T, dh, ldv, nullptr, nullptr, nullptr, 0, 0, 0);
+}
+
+extern "C" int ivit_attention_fused_lut(ivit_handle h, const int8_t *q, const int8_t *k, const int8_t *vt,
+                                        ivit_dyadic dy_qk, float s_softmax, const uint16_t *exp_aq, const float *exp_t,
+                                        const uint8_t *exp_cls, int nclass, int t_count, int dmin, ivit_dyadic dy_pv,
+                                        int8_t *ctx8, int B, int H, int T, int dh, int ldv) {
+    if (h && !(exp_aq && exp_t && exp_cls)) { snprintf(h->err, sizeof(h->err), "ivit_attention_fused_lut: null table"); return IVIT_ERR_INVALID; }
+    return attention_fused_impl(h, q, k, vt, dy_qk, s_softmax, dy_pv, ctx8, B, H, T, dh, ldv, exp_aq, exp_t, exp_cls, nclass, t_count, dmin);
 }
 
 // ---------------------------------------------------------------- requant

@@ -86,7 +86,11 @@ int run_slice(const ivit_vit_s *m, ivit_handle h, const int8_t *images, int B, c
         RUN(ivit_layernorm_requant(h, x, M, D, D, b.s_ln1, b.n1_bias_int, b.n1_sc, b.n1_dy, a8));
         RUN(ivit_linear_i8_qkv(h, a8, b.qkv_w, b.qkv_b, b.qkv_dy, q, k, vt, B, T, H, dh, ld));
         if (m->fused_attention) {
-            RUN(ivit_attention_fused(h, q, k, vt, b.dy_qk, b.s_softmax, b.dy_pv, ctx8, B, H, T, dh, ld));
+            if (b.exp_aq)
+                RUN(ivit_attention_fused_lut(h, q, k, vt, b.dy_qk, b.s_softmax, b.exp_aq, b.exp_t, b.exp_cls, b.exp_nc,
+                                             b.exp_tcount, b.exp_dmin, b.dy_pv, ctx8, B, H, T, dh, ld));
+            else
+                RUN(ivit_attention_fused(h, q, k, vt, b.dy_qk, b.s_softmax, b.dy_pv, ctx8, B, H, T, dh, ld));
         } else {
             int8_t *s8 = (int8_t *)(ws + L.s8);
             uint16_t *p16 = (uint16_t *)(ws + L.p16);

@@ -71,9 +71,12 @@ class ViTEngine:
         for k, (o, dt, shp) in table.items():
             if dt == "<f8" and shp == (1, 2):
                 self.host[k] = hb[o:o + 16].view(np.float64).reshape(1, 2).copy()
+            elif k.endswith("exp_meta"):
+                self.host[k] = hb[o:o + 12].view(np.int32).copy()
         self.h = _lib.Handle(self.device.index or 0, torch.cuda.current_stream(self.device).cuda_stream)
         self._ws = {}
         self.fused_attention = (cfg.head_dim == 64 and cfg.num_tokens <= 640)
+        self.use_exp_tables = True      # forward_ops only: False issues the arithmetic Shiftmax (cross-check)
         # per-layer ShiftGELU(+requant) tables, built on-device by the faithful kernel code
         self.gelu_tab = torch.empty(cfg.depth, 65536, dtype=torch.int8, device=self.device)
         for i in range(cfg.depth):
@@ -96,6 +99,10 @@ class ViTEngine:
             b.s_ln1, b.n1_bias_int, b.n1_sc, b.n1_dy = self.f32[p + "ln1.s"], ptr(p + "norm1.bias_int"), ptr(p + "norm1.sc"), ptr(p + "norm1.dy")
             b.qkv_w, b.qkv_b, b.qkv_dy = ptr(p + "attn.qkv.w"), ptr(p + "attn.qkv.b"), ptr(p + "attn.qkv.dy")
             b.dy_qk, b.s_softmax, b.dy_pv = dy(p + "attn.dy_qk"), self.f32[p + "attn.s_softmax"], dy(p + "attn.dy_pv")
+            if p + "attn.exp_meta" in self.host:        # Shiftmax tables for this layer's scale
+                meta = self.host[p + "attn.exp_meta"]
+                b.exp_aq, b.exp_t, b.exp_cls = ptr(p + "attn.exp_aq"), ptr(p + "attn.exp_t"), ptr(p + "attn.exp_cls")
+                b.exp_nc, b.exp_tcount, b.exp_dmin = int(meta[0]), int(meta[1]), int(meta[2])
             b.proj_w, b.proj_b, b.proj_dy = ptr(p + "attn.proj.w"), ptr(p + "attn.proj.b"), ptr(p + "attn.proj.dy")
             b.res1_main, b.res1_res = dy(p + "res1.dy_main"), dy(p + "res1.dy_res")
             b.s_ln2, b.n2_bias_int, b.n2_sc, b.n2_dy = self.f32[p + "ln2.s"], ptr(p + "norm2.bias_int"), ptr(p + "norm2.sc"), ptr(p + "norm2.dy")
@@ -245,8 +252,15 @@ class ViTEngine:
             call("ivit_linear_i8_qkv", P(ws["a8"]), self.ptr(p + "attn.qkv.w"), self.ptr(p + "attn.qkv.b"),
                  self.ptr(p + "attn.qkv.dy"), P(ws["q"]), P(ws["k"]), P(ws["vt"]), B, T, H, dh, ld)
             if self.fused_attention:
-                call("ivit_attention_fused", P(ws["q"]), P(ws["k"]), P(ws["vt"]), _dy(hc[p + "attn.dy_qk"]),
-                     f32[p + "attn.s_softmax"], _dy(hc[p + "attn.dy_pv"]), P(ws["ctx8"]), B, H, T, dh, ld)
+                if p + "attn.exp_meta" in hc and self.use_exp_tables:
+                    meta = hc[p + "attn.exp_meta"]
+                    call("ivit_attention_fused_lut", P(ws["q"]), P(ws["k"]), P(ws["vt"]), _dy(hc[p + "attn.dy_qk"]),
+                         f32[p + "attn.s_softmax"], self.ptr(p + "attn.exp_aq"), self.ptr(p + "attn.exp_t"),
+                         self.ptr(p + "attn.exp_cls"), int(meta[0]), int(meta[1]), int(meta[2]),
+                         _dy(hc[p + "attn.dy_pv"]), P(ws["ctx8"]), B, H, T, dh, ld)
+                else:
+                    call("ivit_attention_fused", P(ws["q"]), P(ws["k"]), P(ws["vt"]), _dy(hc[p + "attn.dy_qk"]),
+                         f32[p + "attn.s_softmax"], _dy(hc[p + "attn.dy_pv"]), P(ws["ctx8"]), B, H, T, dh, ld)
             else:
                 call("ivit_attn_qk_requant", P(ws["q"]), P(ws["k"]), _dy(hc[p + "attn.dy_qk"]), P(ws["s8"]),
                      B * H, T, dh, ld)

@@ -115,6 +115,10 @@ def freeze_vit(cfg, weights, scales):
         s1 = s[p + "attn.qact1"]
         c[p + "attn.dy_qk"] = dyadic(np.float32(np.float32(s1 * s1) * head_scale), s[p + "attn.qact_attn1"])
         f32[p + "attn.s_softmax"] = s[p + "attn.qact_attn1"]
+        tabs = shiftmax_tables(s[p + "attn.qact_attn1"])
+        if tabs is not None:                       # else: the kernel's arithmetic path for this layer
+            c[p + "attn.exp_aq"], c[p + "attn.exp_t"], c[p + "attn.exp_cls"] = tabs["aq"], tabs["t"], tabs["cls"]
+            c[p + "attn.exp_meta"] = np.array([tabs["NC"], tabs["t"].size, tabs["dmin"]], np.int32)
         c[p + "attn.dy_pv"] = dyadic(np.float32(np.float32(2.0 ** -15) * s1), s[p + "attn.qact2"])
         linear(p + "attn.proj", s[p + "attn.qact2"], p + "attn.qact3")
         c[p + "res1.dy_main"] = dyadic(s[p + "attn.qact3"], s[p + "qact2"])
@@ -133,3 +137,71 @@ def freeze_vit(cfg, weights, scales):
     norm("norm", "qact2")
     c["head.scale"] = linear("head", s["qact2"], None)
     return c, f32
+
+
+# ---------------------------------------------------------------------------------------------------
+# Shiftmax as a table (IntSoftmax.int_exp_shift, quant_modules.py:469-481, for a FROZEN input scale s).
+# A score enters as an 8-bit integer v; the kernel sees x~ = fl(fl(v*s)/s) = v + delta(v), where delta(v) is
+# 0 for ~90 % of v and one of a handful of tiny values otherwise.  The exponent argument is
+# x = fl(x~(v) - x~(vmax)) = fl((v - vmax) + (delta(v) - delta(vmax))): a function of the integer distance
+# d = v - vmax and of eps = delta(v) - delta(vmax), which takes at most a few dozen values per scale.  So
+# exp_int is a table E[eps class][d], a few KB per layer, and the row of classes for a given vmax class is a
+# second small table.  Everything is enumerated with the reference's fp32 operation sequence and then CHECKED
+# against the direct formula for every (vmax, v <= vmax) pair; a layer whose table would not fit is run with
+# the arithmetic path instead.
+def _shift_exp_f32(x, s, n=15):
+    f32 = np.float32
+    x = np.asarray(x, f32)
+    x0 = np.floor(f32(-1.0) / f32(s)).astype(f32)
+    nx0 = f32(n) * x0
+    t = (x + np.floor(x * f32(0.5))).astype(f32)
+    t = (t - np.floor(x * f32(0.0625))).astype(f32)
+    t = np.maximum(t, nx0)
+    q = np.floor((t / x0).astype(f32))
+    r = (t - (x0 * q).astype(f32)).astype(f32)
+    e = ((r * f32(0.5)).astype(f32) - x0).astype(f32)
+    e = np.floor(np.ldexp(e, (n - q.astype(np.int64)).astype(np.int32))).astype(f32)
+    return np.maximum(e, f32(0))
+
+
+def shiftmax_tables(s, max_bytes=24 * 1024):
+    """-> dict(cls uint8[256], aq uint16[NC,256], t float32[NE*R], R, dmin) or None if the tables exceed max_bytes."""
+    f32 = np.float32
+    s = f32(s)
+    v = np.arange(-128, 128).astype(f32)
+    f = ((v * s).astype(f32) / s).astype(f32)                 # x~(v)
+    delta = f.astype(np.float64) - v.astype(np.float64)       # exact
+    dvals = np.unique(delta)
+    cls = np.searchsorted(dvals, delta).astype(np.uint8)
+    NC = len(dvals)
+    eps_vals = np.unique(dvals[:, None] - dvals[None, :])
+    NE = len(eps_vals)
+    d_all = np.arange(-255, 1)
+    # E over every (eps, d); the argument is the single fp32 rounding of the exact real d + eps
+    X = (d_all[None, :].astype(np.float64) + eps_vals[:, None]).astype(f32)
+    E = _shift_exp_f32(X, s)                                   # [NE, 256]
+    # positive arguments (d = 0, eps > 0) cannot occur: vmax maximises x~ — they are never indexed
+    const = E[:, 0]
+    if not np.all(const == const[0]):
+        return None
+    same = np.all(E == const[0], axis=0)                       # per d: every eps class at the floor value
+    k = 0
+    while k + 1 < 256 and same[k + 1]:
+        k += 1
+    dmin = int(d_all[k])
+    R = -dmin + 1
+    if NE * R * 4 + NC * 512 + 256 > max_bytes or NE * R >= 65536:
+        return None
+    T = np.ascontiguousarray(E[:, k:]).astype(f32)              # [NE, R], column dd = d - dmin
+    eid = np.searchsorted(eps_vals, dvals[:, None] - dvals[None, :])      # [class of v][class of vmax]
+    aq = (eid[cls][:, :].T.astype(np.int64) * R).astype(np.uint16)        # [NC (vmax class), 256 (v)]
+    # exhaustive check against the direct formula
+    vi = np.arange(256)
+    for qi in range(256):
+        x = (f[: qi + 1] - f[qi]).astype(f32)
+        direct = _shift_exp_f32(x, s)
+        dd = np.maximum(vi[: qi + 1] - qi, dmin) - dmin
+        tab = T.reshape(-1)[aq[cls[qi], : qi + 1].astype(np.int64) + dd]
+        if not np.array_equal(direct, tab):
+            raise AssertionError(f"shiftmax table mismatch at vmax index {qi} for scale {float(s)!r}")
+    return dict(cls=cls, aq=np.ascontiguousarray(aq), t=T.reshape(-1), R=R, dmin=dmin, NC=NC, NE=NE)

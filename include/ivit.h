@@ -122,6 +122,15 @@ int ivit_attention_fused(ivit_handle h, const int8_t *q, const int8_t *k, const 
                          ivit_dyadic dy_qk, float s_softmax, ivit_dyadic dy_pv, int8_t *ctx8,
                          int B, int H, int T, int dh, int ldv);
 
+/* The same with Shiftmax's exp_int taken from tables built on the host for the layer's frozen scale
+ * (ivit_amd.freeze.shiftmax_tables; exhaustively checked against the arithmetic form when built):
+ * exp_int = exp_t[exp_aq[exp_cls[vmax]][v] + max(v - vmax, dmin) - dmin].  exp_aq uint16 [nclass][256],
+ * exp_t float [t_count], exp_cls uint8 [256] (device).  Same integers as ivit_attention_fused.        */
+int ivit_attention_fused_lut(ivit_handle h, const int8_t *q, const int8_t *k, const int8_t *vt,
+                             ivit_dyadic dy_qk, float s_softmax, const uint16_t *exp_aq, const float *exp_t,
+                             const uint8_t *exp_cls, int nclass, int t_count, int dmin, ivit_dyadic dy_pv,
+                             int8_t *ctx8, int B, int H, int T, int dh, int ldv);
+
 /* ---- a3  QuantAct.forward with a previous scale -> fixedpoint_mul.forward
  * (quant_modules.py:197-206, quant_utils.py:192-253).  z int32 or float (integer-valued;
  * the I-LayerNorm output exceeds int32), [rows, C];  dy has nch = 1 or C entries;
@@ -202,6 +211,8 @@ typedef struct ivit_vit_block {
        attn.v -> qact2 (:77-79); proj -> qact3 (:80-82) */
     const int8_t *qkv_w; const int32_t *qkv_b; const ivit_dyadic *qkv_dy;
     ivit_dyadic dy_qk; float s_softmax; ivit_dyadic dy_pv;
+    const uint16_t *exp_aq; const float *exp_t; const uint8_t *exp_cls;   /* optional Shiftmax tables (NULL: arithmetic) */
+    int exp_nc, exp_tcount, exp_dmin;
     const int8_t *proj_w; const int32_t *proj_b; const ivit_dyadic *proj_dy;
     ivit_dyadic res1_main, res1_res;                       /* qact2 with identity (:134) */
     /* norm2 -> qact3 (:135-136); mlp (layers_quant.py:144-153); qact4 with identity (:138) */

@@ -721,3 +721,29 @@ def test_random_shapes_self_calibrated_engine_vs_oracle(spec):
     with torch.no_grad():
         acc, _ = m(dev(imgs))
     assert np.array_equal(acc.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("scale", [0.3036, 0.2306, 0.1947, 0.1059, 0.52, 0.0902])
+def test_attention_shiftmax_tables_equal_arithmetic(H, scale):
+    """ivit_attention_fused_lut (exp_int from the host-built (eps class, distance) tables) == ivit_attention_fused
+    (fp32 arithmetic replay) for scales with 1 ... 13 requotient classes, ragged T and saturated scores."""
+    tabs = iv.freeze.shiftmax_tables(np.float32(scale))
+    assert tabs is not None
+    rng = np.random.default_rng(int(scale * 1e4))
+    B, Hh, dh = 2, 3, 64
+    for T in (197, 50, 577):
+        ld = (T + 15) // 16 * 16
+        q = dev(rng.integers(-128, 128, (B * Hh, T, dh), dtype=np.int8))
+        k = dev(rng.integers(-128, 128, (B * Hh, T, dh), dtype=np.int8))
+        vt = np.zeros((B * Hh, dh, ld), np.int8)
+        vt[:, :, :T] = rng.integers(-128, 128, (B * Hh, dh, T), dtype=np.int8)
+        vt = dev(vt)
+        dqk = iv.freeze.dyadic(np.float32(2.2e-4), np.float32(scale))     # scores spread over the whole int8 range
+        dpv = iv.freeze.dyadic(np.float32(2.0 ** -15 * 0.1), np.float32(0.05))
+        o1 = torch.empty(B, T, Hh * dh, dtype=torch.int8, device="cuda")
+        o2 = torch.full_like(o1, 9)
+        H.call("ivit_attention_fused", P(q), P(k), P(vt), dyv(dqk), float(scale), dyv(dpv), P(o1), B, Hh, T, dh, ld)
+        H.call("ivit_attention_fused_lut", P(q), P(k), P(vt), dyv(dqk), float(scale), P(dev(tabs["aq"])), P(dev(tabs["t"])),
+               P(dev(tabs["cls"])), int(tabs["NC"]), int(tabs["t"].size), int(tabs["dmin"]), dyv(dpv), P(o2), B, Hh, T, dh, ld)
+        assert np.array_equal(o1.cpu().numpy(), o2.cpu().numpy()), (scale, T)
+        assert len(np.unique(o1.cpu().numpy())) > 20

@@ -136,3 +136,29 @@ def test_swin_oracle_vs_reference(fname, full):
         if full:
             ref = g["site/" + n]
             assert np.array_equal(np.asarray(cap[n]).reshape(ref.shape).astype(np.float64), ref.astype(np.float64)), n
+
+
+def test_shiftmax_tables_reproduce_oracle_shiftmax():
+    """host-built Shiftmax exp tables (ivit_amd.freeze.shiftmax_tables) + the rest of the Shiftmax arithmetic
+    (torch-order row sum, factor, shift) == the C oracle's Shiftmax on random rows, for scales with 1..13
+    requotient classes; and the builder refuses (returns None) rather than overflow its budget."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(9)
+    for scale in (0.3036, 0.2306, 0.1947, 0.2508, 0.1059, 0.52):
+        tabs = iv.freeze.shiftmax_tables(np.float32(scale))
+        assert tabs is not None and tabs["t"].size == tabs["NE"] * tabs["R"] and tabs["aq"].shape == (tabs["NC"], 256)
+        for n in (49, 197):
+            x = rng.integers(-128, 128, (64, n), dtype=np.int8)
+            x[0] = 127; x[1] = -128; x[2, 1:] = -128
+            ref = orc.shiftmax(x, np.float32(scale), 16).astype(np.int64)
+            vmax = x.max(axis=1, keepdims=True).astype(np.int64)
+            xi = x.astype(np.int64)
+            idx = tabs["aq"][tabs["cls"][vmax[:, 0] + 128]][np.arange(64)[:, None], xi + 128].astype(np.int64) \
+                + np.maximum(xi - vmax, tabs["dmin"]) - tabs["dmin"]
+            e = tabs["t"][idx].astype(np.float32)
+            S = np.array([orc.torch_sum(row) for row in e], np.float32)
+            S = np.minimum(S, np.float32(2147483648.0))
+            F = np.floor((np.float32(1.0) / S).astype(np.float32) * np.float32(2147483648.0)).astype(np.float32)
+            got = np.floor(((e * F[:, None]).astype(np.float32)) * np.float32(2.0 ** -16)).astype(np.int64)
+            assert np.array_equal(got, ref), (scale, n)
+    assert iv.freeze.shiftmax_tables(np.float32(0.2306), max_bytes=4096) is None      # 57 classes x 54 do not fit 4 KB
