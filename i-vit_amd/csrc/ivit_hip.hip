@@ -657,7 +657,7 @@ int ivit_mlp_fused(ivit_handle h, const int8_t *x, const int8_t *w1, const int32
     a.dy_main = dy_main; a.dy_res = dy_res; a.residual = residual; a.out = out; a.M = M;
     const long long ntiles = (M + MF_BM - 1) / MF_BM;
     const unsigned grid = (unsigned)(ntiles < h->num_cu ? ntiles : h->num_cu);
-    swin_mlp_fused_kernel<<<grid, 512, MF_SMEM, h->stream>>>(a);
+    swin_mlp_fused_kernel<<<grid, MF_THREADS, MF_SMEM, h->stream>>>(a);
     LAUNCH_CHECK(h);
     return IVIT_OK;
 }

@@ -482,7 +482,8 @@ struct MlpFusedArgs {
 #define MF_MAX (MF_B2 + MF_C * 4)                    // 132736: 64 ints
 #define MF_SMEM (MF_MAX + MF_BM * 4)                 // 132992
 
-__global__ __launch_bounds__(512) void swin_mlp_fused_kernel(MlpFusedArgs p) {
+#define MF_THREADS 1024
+__global__ __launch_bounds__(MF_THREADS) void swin_mlp_fused_kernel(MlpFusedArgs p) {
     extern __shared__ __attribute__((aligned(16))) char sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     double *sC1 = reinterpret_cast<double *>(sm + MF_C1), *sC2 = reinterpret_cast<double *>(sm + MF_C2);
@@ -490,12 +491,12 @@ __global__ __launch_bounds__(512) void swin_mlp_fused_kernel(MlpFusedArgs p) {
     int *sMax = reinterpret_cast<int *>(sm + MF_MAX);
 
     // ---- one-off: weights -> LDS in fragment (chunk-major) layout, constants
-    for (int i = tid; i < MF_HD * MF_C / 16; i += 512) {          // W1 [384][96]: 6 chunks of 16 B per row
+    for (int i = tid; i < MF_HD * MF_C / 16; i += MF_THREADS) {          // W1 [384][96]: 6 chunks of 16 B per row
         const int n = i / 6, c16 = i - n * 6, kc = c16 >> 1, hh = c16 & 1;
         *reinterpret_cast<v4i *>(sm + MF_W1 + kc * (MF_HD * 32) + n * 32 + hh * 16) =
             *reinterpret_cast<const v4i *>(p.w1 + n * MF_C + c16 * 16);
     }
-    for (int i = tid; i < MF_C * MF_HD / 16; i += 512) {          // W2 [96][384]: 24 chunks per row
+    for (int i = tid; i < MF_C * MF_HD / 16; i += MF_THREADS) {          // W2 [96][384]: 24 chunks per row
         const int n = i / 24, c16 = i - n * 24, kc = c16 >> 1, hh = c16 & 1;
         *reinterpret_cast<v4i *>(sm + MF_W2 + kc * (MF_C * 32) + n * 32 + hh * 16) =
             *reinterpret_cast<const v4i *>(p.w2 + n * MF_HD + c16 * 16);
@@ -523,11 +524,20 @@ __global__ __launch_bounds__(512) void swin_mlp_fused_kernel(MlpFusedArgs p) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();                                          // X(tile) landed; H / rows free again
         if (tile + gridDim.x < ntiles) issue_x(tile + gridDim.x, buf ^ 1);
-        const char *sX = sm + MF_X + buf * (MF_BM * MF_C);
-        // ---- S1: fc1, 3 (n-tile, m-tile) units per wave
+        // identity rows of this tile for S4 (waves 0..5): requested now, consumed four phases later
+        v4i rsv[2] = {v4i{0, 0, 0, 0}, v4i{0, 0, 0, 0}};
+        if (wave < 6) {
+            const long long tok = tile * MF_BM + (wave & 1) * 32 + l31;
+            if (tok < p.M) {
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            const int unit = wave * 3 + u, nt = unit >> 1, mt = unit & 1;
+                for (int q = 0; q < 2; ++q)
+                    rsv[q] = *reinterpret_cast<const v4i *>(p.residual + tok * MF_C + (wave >> 1) * 32 + half * 16 + q * 8);
+            }
+        }
+        const char *sX = sm + MF_X + buf * (MF_BM * MF_C);
+        // ---- S1: fc1, 24 (n-tile, m-tile) units over the wavefronts
+        for (int unit = wave; unit < 24; unit += MF_THREADS / 64) {
+            const int nt = unit >> 1, mt = unit & 1;
             v16i_sw acc;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -562,16 +572,16 @@ __global__ __launch_bounds__(512) void swin_mlp_fused_kernel(MlpFusedArgs p) {
         __syncthreads();
         // ---- S2: the table row of each token's max -> LDS (64 rows x 256 B = 1024 chunks of 16 B)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int ch = tid + i * 512, t = ch >> 4, c16 = ch & 15;
+        for (int i = 0; i < 1024 / MF_THREADS; ++i) {
+            const int ch = tid + i * MF_THREADS, t = ch >> 4, c16 = ch & 15;
             *reinterpret_cast<v4i *>(sm + MF_ROWS + t * 256 + c16 * 16) =
                 *reinterpret_cast<const v4i *>(p.tab + (sMax[t] + 128) * 256 + c16 * 16);
         }
         __syncthreads();
-        // ---- S3: ShiftGELU(+requant) by table, in place: 24576 bytes = 6144 dwords, 12 per thread
+        // ---- S3: ShiftGELU(+requant) by table, in place: 24576 bytes = 6144 dwords
 #pragma unroll
-        for (int i = 0; i < 12; ++i) {
-            const int dw = tid + i * 512;                          // dword index in H: [kc][token][8 dwords]
+        for (int i = 0; i < 6144 / MF_THREADS; ++i) {
+            const int dw = tid + i * MF_THREADS;                          // dword index in H: [kc][token][8 dwords]
             const int t = (dw >> 3) & (MF_BM - 1);
             const unsigned char *L = reinterpret_cast<const unsigned char *>(sm + MF_ROWS + t * 256);
             unsigned *hp = reinterpret_cast<unsigned *>(sm + MF_H) + dw;
@@ -617,7 +627,7 @@ __global__ __launch_bounds__(512) void swin_mlp_fused_kernel(MlpFusedArgs p) {
                 const int ch0 = nt * 32 + half * 16 + q * 8;
                 if (tok < p.M) {
                     const long long off = tok * MF_C + ch0;
-                    const v4i rs = *reinterpret_cast<const v4i *>(p.residual + off);
+                    const v4i rs = rsv[q];
 #pragma unroll
                     for (int w = 0; w < 4; ++w) {
                         const int t0 = (int)(short)(v[w] & 0xffff), t1 = v[w] >> 16;
