@@ -257,9 +257,9 @@ class SwinTransformer(nn.Module):
         # avgpool over tokens + qact3 (swin_quant.py:553-555), fused: one C-ABI call
         B, L, C = x.shape
         if self.qact3.running_stat:
-            # calibration: the range of the pooled fp32 activations, pooled with the reference's own op on
-            # the host (swin_quant.py:553-554) so the statistic sees the same fp32 values
-            X = (x.float() * torch.as_tensor(_f32(s), device=x.device)).cpu()
+            # calibration: the range of the pooled fp32 activations, pooled with the reference's own op
+            # (swin_quant.py:553-554) on the device
+            X = x.float() * torch.as_tensor(_f32(s), device=x.device)
             pooled = torch.nn.functional.adaptive_avg_pool1d(X.transpose(1, 2), 1).flatten(1)
             self.qact3._collect_range(pooled, None, None, None)
         s3 = np.float32(self.qact3.act_scaling_factor.reshape(-1)[0].item())
