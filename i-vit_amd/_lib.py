@@ -10,7 +10,7 @@ import subprocess
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 SO_PATH = os.environ.get("IVIT_LIB") or os.path.join(_CSRC, "libivit_hip.so")
 SOURCES = ["ivit_hip.hip", "ivit_device.h", "ivit_gemm.h", "ivit_elementwise.h", "ivit_attention.h", "ivit_gemm2.h", "ivit_swin.h", "ivit_model.h"]
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-pass-failed", "-fPIC", "-shared"]
 
 
 class IvitError(RuntimeError):

@@ -66,6 +66,12 @@ int ivit_set_stream(ivit_handle h, void *hip_stream) {
 
 const char *ivit_last_error(ivit_handle h) { return h ? h->err : "null handle"; }
 
+// tuning / ablation switches are read once per process (thread-safe static initialisation at the call site)
+static int env_int(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
 static inline int grid_for(ivit_handle h, long long work_items, int per_block) {
     long long g = (work_items + per_block - 1) / per_block;
     long long cap = (long long)h->num_cu * 16;
@@ -115,9 +121,8 @@ static int launch_gemm(ivit_handle h, GemmArgs &a, int nb) {
 template <int EPI>
 static int launch_gemm2(ivit_handle h, GemmArgs &a) {
     a.tiles_n = (a.N + G2_BN - 1) / G2_BN;
-    { static int dbg = -1; if (dbg < 0) { const char *e = getenv("IVIT_GEMM_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
-    static int force_bm = -1;
-    if (force_bm < 0) { const char *e = getenv("IVIT_GEMM_BM"); force_bm = e ? atoi(e) : 0; }
+    static const int dbg = env_int("IVIT_GEMM_DBG", 0), force_bm = env_int("IVIT_GEMM_BM", 0);
+    a.dbg = dbg;
     // tile height: estimated time ~ ceil(tiles / resident slots) * rows per tile; 256-row tiles run
     // 2 per CU, 128-row tiles 3 per CU.  Ties go to the larger tile (better operand reuse).
     const long long t256 = (long long)((a.M + 255) / 256) * a.tiles_n, t128 = (long long)((a.M + 127) / 128) * a.tiles_n;
@@ -268,9 +273,8 @@ template <int NB>
 static int launch_attn(ivit_handle h, const AttnArgs &a, int BH) {
     const double cq = a.dy_qk.m * a.dy_qk.r, cp = a.dy_pv.m * a.dy_pv.r;
     const bool fast = (cq < 512.0 && cq > -512.0 && cp < 512.0 && cp > -512.0);
-    static int dyn_t = -1, no_lut = -1;   // IVIT_ATTN_DYNAMIC_T=1 / IVIT_ATTN_NO_LUT=1: generic forms (A/B, tests)
-    if (dyn_t < 0) { const char *e = getenv("IVIT_ATTN_DYNAMIC_T"); dyn_t = e ? atoi(e) : 0; }
-    if (no_lut < 0) { const char *e = getenv("IVIT_ATTN_NO_LUT"); no_lut = e ? atoi(e) : 0; }
+    // IVIT_ATTN_DYNAMIC_T=1 / IVIT_ATTN_NO_LUT=1: generic forms (A/B, tests)
+    static const int dyn_t = env_int("IVIT_ATTN_DYNAMIC_T", 0), no_lut = env_int("IVIT_ATTN_NO_LUT", 0);
     const bool lut = a.aq && a.et && a.cls && !no_lut;
     if (fast && !dyn_t) {
         if (NB == 4 && a.T == 197) return lut ? launch_attn2<NB, true, 197, true>(h, a, BH) : launch_attn2<NB, true, 197>(h, a, BH);
@@ -453,14 +457,13 @@ int ivit_layernorm_requant(ivit_handle h, const int16_t *x, int64_t rows, int C,
     REQUIRE(h, (C % 8) == 0 && (row_stride % 8) == 0 && row_stride >= C, "C, row_stride multiples of 8");
     {   // production form: 16 lanes per row, constants staged in LDS
         const size_t lds16 = (size_t)16 * (C + 16) * 4 + (size_t)C * 20;
-        static int ln_old = -1;
-        if (ln_old < 0) { const char *e = getenv("IVIT_LN_OLD"); ln_old = e ? atoi(e) : 0; }
+        static const int ln_old = env_int("IVIT_LN_OLD", 0), force_riter = env_int("IVIT_LN_RITER", 0);
         if (lds16 <= 150 * 1024 && !ln_old) {
             // row groups per block: up to LN_RITER (amortises the constant staging), fewer when the launch would
             // otherwise leave CUs idle (>= 3 blocks per CU wanted)
             long long riter = rows / (16LL * 3 * h->num_cu);
             riter = riter < 1 ? 1 : (riter > LN_RITER ? LN_RITER : riter);
-            { static int force = -1; if (force < 0) { const char *e = getenv("IVIT_LN_RITER"); force = e ? atoi(e) : 0; } if (force > 0) riter = force; }
+            if (force_riter > 0) riter = force_riter;
             const long long per_block = 16 * riter;
             const unsigned grid = (unsigned)((rows + per_block - 1) / per_block);
 #define LN16_LAUNCH(CC)                                                                                   \

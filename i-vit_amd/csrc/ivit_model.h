@@ -149,24 +149,26 @@ int ivit_vit_create(ivit_handle h, const ivit_vit_config *cfg, const ivit_vit_pa
     }
     for (int i = 0; i < cfg->depth; ++i) {
         int rc = ivit_shiftgelu_build_table(h, m->blocks[i].s_gelu, m->blocks[i].dy_gelu, m->gelu_tab + (size_t)i * 65536);
-        if (rc != IVIT_OK) { hipFree(m->gelu_tab); delete m; return rc; }
+        if (rc != IVIT_OK) { (void)hipFree(m->gelu_tab); delete m; return rc; }
     }
     if (max_slices > 1) {
-        hipEventCreateWithFlags(&m->fork, hipEventDisableTiming);
-        for (int i = 0; i < max_slices; ++i) {
-            hipStream_t st;
-            hipEvent_t ev;
-            if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess ||
-                hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
-                snprintf(h->err, sizeof(h->err), "ivit_vit_create: stream/event creation failed");
-                ivit_vit_destroy(m);
-                return IVIT_ERR_HIP;
-            }
+        bool ok = hipEventCreateWithFlags(&m->fork, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; ok && i < max_slices; ++i) {
+            // each resource is owned by `m` as soon as it exists, so the destroy on the error path releases it
+            hipStream_t st = nullptr;
+            hipEvent_t ev = nullptr;
             ivit_handle sh = nullptr;
-            ivit_create(&sh, h->device, st);
-            m->streams.push_back(st);
-            m->done.push_back(ev);
-            m->slice_h.push_back(sh);
+            ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+            if (ok) m->streams.push_back(st);
+            ok = ok && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
+            if (ok) m->done.push_back(ev);
+            ok = ok && ivit_create(&sh, h->device, st) == IVIT_OK;
+            if (ok) m->slice_h.push_back(sh);
+        }
+        if (!ok) {
+            snprintf(h->err, sizeof(h->err), "ivit_vit_create: stream/event creation failed");
+            ivit_vit_destroy(m);
+            return IVIT_ERR_HIP;
         }
     }
     *out = m;
@@ -176,10 +178,10 @@ int ivit_vit_create(ivit_handle h, const ivit_vit_config *cfg, const ivit_vit_pa
 int ivit_vit_destroy(ivit_vit m) {
     if (!m) return IVIT_ERR_INVALID;
     for (auto sh : m->slice_h) ivit_destroy(sh);
-    for (auto ev : m->done) hipEventDestroy(ev);
-    for (auto st : m->streams) hipStreamDestroy(st);
-    if (m->fork) hipEventDestroy(m->fork);
-    if (m->gelu_tab) hipFree(m->gelu_tab);
+    for (auto ev : m->done) (void)hipEventDestroy(ev);
+    for (auto st : m->streams) (void)hipStreamDestroy(st);
+    if (m->fork) (void)hipEventDestroy(m->fork);
+    if (m->gelu_tab) (void)hipFree(m->gelu_tab);
     delete m;
     return IVIT_OK;
 }
@@ -248,11 +250,11 @@ int ivit_vit_graph_create(ivit_vit m, const int8_t *images, int batch, int nslic
     int rc = ivit_vit_forward(m, images, batch, nslices, workspace, bytes, logits);
     hipGraph_t graph = nullptr;
     e = hipStreamEndCapture(h->stream, &graph);
-    if (rc != IVIT_OK) { if (graph) hipGraphDestroy(graph); return rc; }
+    if (rc != IVIT_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
     if (e != hipSuccess || !graph) { snprintf(h->err, sizeof(h->err), "end capture: %s", hipGetErrorString(e)); return IVIT_ERR_HIP; }
     hipGraphExec_t exec = nullptr;
     e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    if (e != hipSuccess) { hipGraphDestroy(graph); snprintf(h->err, sizeof(h->err), "instantiate: %s", hipGetErrorString(e)); return IVIT_ERR_HIP; }
+    if (e != hipSuccess) { (void)hipGraphDestroy(graph); snprintf(h->err, sizeof(h->err), "instantiate: %s", hipGetErrorString(e)); return IVIT_ERR_HIP; }
     ivit_graph_s *g = new ivit_graph_s();
     g->h = h; g->graph = graph; g->exec = exec;
     *out = g;
@@ -268,8 +270,8 @@ int ivit_graph_launch(ivit_graph g) {
 
 int ivit_graph_destroy(ivit_graph g) {
     if (!g) return IVIT_ERR_INVALID;
-    hipGraphExecDestroy(g->exec);
-    hipGraphDestroy(g->graph);
+    (void)hipGraphExecDestroy(g->exec);
+    (void)hipGraphDestroy(g->graph);
     delete g;
     return IVIT_OK;
 }
@@ -394,10 +396,10 @@ extern "C" {
 int ivit_swin_destroy(ivit_swin m) {
     if (!m) return IVIT_ERR_INVALID;
     for (auto sh : m->slice_h) ivit_destroy(sh);
-    for (auto ev : m->done) hipEventDestroy(ev);
-    for (auto st : m->streams) hipStreamDestroy(st);
-    if (m->fork) hipEventDestroy(m->fork);
-    if (m->gelu_tab) hipFree(m->gelu_tab);
+    for (auto ev : m->done) (void)hipEventDestroy(ev);
+    for (auto st : m->streams) (void)hipStreamDestroy(st);
+    if (m->fork) (void)hipEventDestroy(m->fork);
+    if (m->gelu_tab) (void)hipFree(m->gelu_tab);
     delete m;
     return IVIT_OK;
 }
@@ -427,7 +429,7 @@ int ivit_swin_create(ivit_handle h, const ivit_swin_config *cfg, const ivit_swin
     m->blocks.assign(params->blocks_host, params->blocks_host + nb);
     if (cfg->num_layers > 1) m->merges.assign(params->merges_host, params->merges_host + cfg->num_layers - 1);
     m->grid = grid; m->nblocks = nb; m->gelu_tab = nullptr; m->max_slices = max_slices; m->fork = nullptr;
-    { const char *e = getenv("IVIT_SWIN_FUSED_MLP"); m->fused_mlp = e ? atoi(e) != 0 : true; }
+    m->fused_mlp = env_int("IVIT_SWIN_FUSED_MLP", 1) != 0;
     if (hipMemcpy(&m->dy_qact1_host, params->dy_qact1, sizeof(ivit_dyadic), hipMemcpyDeviceToHost) != hipSuccess) {
         snprintf(h->err, sizeof(h->err), "ivit_swin_create: cannot read dy_qact1");
         delete m;
@@ -443,19 +445,23 @@ int ivit_swin_create(ivit_handle h, const ivit_swin_config *cfg, const ivit_swin
         if (rc != IVIT_OK) { ivit_swin_destroy(m); return rc; }
     }
     if (max_slices > 1) {
-        hipEventCreateWithFlags(&m->fork, hipEventDisableTiming);
-        for (int i = 0; i < max_slices; ++i) {
-            hipStream_t st;
-            hipEvent_t ev;
-            if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess ||
-                hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
-                snprintf(h->err, sizeof(h->err), "ivit_swin_create: stream/event creation failed");
-                ivit_swin_destroy(m);
-                return IVIT_ERR_HIP;
-            }
+        bool ok = hipEventCreateWithFlags(&m->fork, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; ok && i < max_slices; ++i) {
+            // each resource is owned by `m` as soon as it exists, so the destroy on the error path releases it
+            hipStream_t st = nullptr;
+            hipEvent_t ev = nullptr;
             ivit_handle sh = nullptr;
-            ivit_create(&sh, h->device, st);
-            m->streams.push_back(st); m->done.push_back(ev); m->slice_h.push_back(sh);
+            ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+            if (ok) m->streams.push_back(st);
+            ok = ok && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
+            if (ok) m->done.push_back(ev);
+            ok = ok && ivit_create(&sh, h->device, st) == IVIT_OK;
+            if (ok) m->slice_h.push_back(sh);
+        }
+        if (!ok) {
+            snprintf(h->err, sizeof(h->err), "ivit_swin_create: stream/event creation failed");
+            ivit_swin_destroy(m);
+            return IVIT_ERR_HIP;
         }
     }
     *out = m;
@@ -506,11 +512,11 @@ int ivit_swin_graph_create(ivit_swin m, const int8_t *images, int batch, int nsl
     int rc = ivit_swin_forward(m, images, batch, nslices, workspace, bytes, logits);
     hipGraph_t graph = nullptr;
     e = hipStreamEndCapture(h->stream, &graph);
-    if (rc != IVIT_OK) { if (graph) hipGraphDestroy(graph); return rc; }
+    if (rc != IVIT_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
     if (e != hipSuccess || !graph) { snprintf(h->err, sizeof(h->err), "end capture: %s", hipGetErrorString(e)); return IVIT_ERR_HIP; }
     hipGraphExec_t exec = nullptr;
     e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    if (e != hipSuccess) { hipGraphDestroy(graph); snprintf(h->err, sizeof(h->err), "instantiate: %s", hipGetErrorString(e)); return IVIT_ERR_HIP; }
+    if (e != hipSuccess) { (void)hipGraphDestroy(graph); snprintf(h->err, sizeof(h->err), "instantiate: %s", hipGetErrorString(e)); return IVIT_ERR_HIP; }
     ivit_graph_s *g = new ivit_graph_s();
     g->h = h; g->graph = graph; g->exec = exec;
     *out = g;
