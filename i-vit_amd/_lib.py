@@ -9,7 +9,7 @@ import subprocess
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 SO_PATH = os.environ.get("IVIT_LIB") or os.path.join(_CSRC, "libivit_hip.so")
-SOURCES = ["ivit_hip.hip", "ivit_device.h", "ivit_gemm.h", "ivit_elementwise.h", "ivit_attention.h", "ivit_gemm2.h", "ivit_swin.h", "ivit_model.h"]
+SOURCES = ["ivit_hip.hip", "ivit_device.h", "ivit_gemm.h", "ivit_elementwise.h", "ivit_attention.h", "ivit_gemm2.h", "ivit_gemm3.h", "ivit_swin.h", "ivit_model.h"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-pass-failed", "-fPIC", "-shared"]
 
 
@@ -151,6 +151,10 @@ SIGNATURES = {
     "ivit_linear_i8_requant": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I],
     "ivit_linear_i8_requant_residual": [_P, _P, _P, _P, _P, Dyadic, Dyadic, _P, _P, _I, _I, _I],
     "ivit_linear_i8_qkv": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I],
+    "ivit_linear_plan_create": [_P, _P, _P, _P, _I, _I, ctypes.POINTER(_P)],
+    "ivit_linear_i8_requant_planned": [_P, _P, _P, _I, _P, _I],
+    "ivit_linear_i8_requant_residual_planned": [_P, _P, _P, Dyadic, Dyadic, _P, _P, _I],
+    "ivit_linear_i8_qkv_planned": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I],
     "ivit_bmm_nt_i8": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _L, _L],
     "ivit_bmm_nt_u16i8": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _L, _L],
     "ivit_attn_qk_requant": [_P, _P, _P, Dyadic, _P, _I, _I, _I, _I],
@@ -174,7 +178,7 @@ SIGNATURES = {
     "ivit_im2col_patch": [_P, _P, _I, _I, _I, _I, _I, _P],
     "ivit_embed_finish": [_P, _P, _P, _P, Dyadic, Dyadic, _P, _I, _I, _I],
 }
-OTHER_SYMBOLS = ["ivit_version", "ivit_status_string", "ivit_last_error"]
+OTHER_SYMBOLS = ["ivit_version", "ivit_status_string", "ivit_last_error", "ivit_linear_plan_destroy", "ivit_linear_plan_query", "ivit_debug_plan_scratch"]
 
 _lib = None
 
@@ -197,6 +201,12 @@ def load():
     lib.ivit_status_string.argtypes = [ctypes.c_int]
     lib.ivit_last_error.restype = ctypes.c_char_p
     lib.ivit_last_error.argtypes = [_P]
+    lib.ivit_linear_plan_destroy.argtypes = [_P]
+    lib.ivit_linear_plan_destroy.restype = ctypes.c_int
+    lib.ivit_linear_plan_query.argtypes = [_P, ctypes.POINTER(_I), ctypes.POINTER(_I)]
+    lib.ivit_linear_plan_query.restype = ctypes.c_int
+    lib.ivit_debug_plan_scratch.argtypes = [_P, _P, _I]
+    lib.ivit_debug_plan_scratch.restype = ctypes.c_int
     _lib = lib
     return lib
 
@@ -224,10 +234,39 @@ class Handle:
     def call(self, name, *args):
         self._check(getattr(self.lib, name)(self.h, *args), name)
 
+    def linear_plan(self, w, bias, dy, N, K):
+        """ivit_linear_plan_create: returns a LinearPlan (frozen QuantLinear: w/bias/dy device pointers must outlive it)."""
+        return LinearPlan(self, w, bias, dy, N, K)
+
     def close(self):
         if self.h:
             self.lib.ivit_destroy(self.h)
             self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class LinearPlan:
+    """ivit_linear_plan: per-channel multipliers + exactness bounds of one frozen QuantLinear (include/ivit.h)."""
+
+    def __init__(self, handle, w, bias, dy, N, K):
+        self.lib = handle.lib
+        p = _P()
+        handle._check(self.lib.ivit_linear_plan_create(handle.h, w, bias, dy, int(N), int(K), ctypes.byref(p)),
+                      "ivit_linear_plan_create")
+        self.p = p
+        a, b = _I(0), _I(0)
+        self.lib.ivit_linear_plan_query(p, ctypes.byref(a), ctypes.byref(b))
+        self.pipelined_ok, self.single_fma_ok = bool(a.value), bool(b.value)
+
+    def close(self):
+        if self.p:
+            self.lib.ivit_linear_plan_destroy(self.p)
+            self.p = None
 
     def __del__(self):
         try:

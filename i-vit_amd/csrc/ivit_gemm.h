@@ -35,6 +35,8 @@ struct GemmArgs {
     long long sC_outer, sC_inner;
     const int32_t *bias;
     const ivit_dyadic *dy_ch;
+    const double *cq;    // per-channel c = m * 2^-e, precomputed by the linear plan (gemm_ps_kernel)
+    void *dummy;         // >= 1 KB of device scratch: where lanes outside the matrix store (gemm_as_kernel)
     ivit_dyadic dy_main, dy_res;
     const int16_t *residual;
     void *out;

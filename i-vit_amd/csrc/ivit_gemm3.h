@@ -1,0 +1,862 @@
+// ivit_gemm3.h — persistent, software-pipelined int8 GEMMs for the QuantLinear layers
+// (K % 64 == 0, K >= 320, N % 16 == 0): the production kernels of the DeiT/ViT path.
+//
+//   C = A (M x K int8) * W^T (W: N x K int8) + bias, fused requant epilogues (a1 + a3 [+ a3 identity]).
+//
+// Why: at K = 384 a 128 x 128 tile is 48 MFMAs per wave.  A launch-per-tile kernel spends as long waiting
+// for its first operands and running its requant epilogue as it spends in MFMAs, and — measured with the
+// ablation switches below — the operand stream alone (global_load_lds, L2 -> LDS) of a 128- or 256-row
+// tiling takes 41 us of fc1's 55: ~11 TB/s is what the chip's L2 -> LDS path delivers, and 1/64 B per MAC
+// is more than an int8 MFMA GEMM can afford.  One kernel template, two modes:
+//
+//   * ASTAT = true (K <= 384: qkv, proj, fc1) — A-STATIONARY.  One workgroup per CU (8 waves, 256
+//     registers each) owns a contiguous range of (256-token panel, 128-channel tile) units.  The panel
+//     (256 x K int8 = 96 KB) stays in LDS; its 64-column slices arrive lazily, together with the weight
+//     slices, during the panel's first unit.  Every later unit of the panel streams ONLY the 8 KB weight
+//     slice per k-step: 1/256 B per MAC instead of 1/64..1/85.
+//   * ASTAT = false (K > 384: fc2) — STREAMING.  Two workgroups per CU (4 waves each) walk lists of
+//     128 x 128 tiles; A and W slices both go through the ring.
+//
+// Common to both:
+//   * persistent: the (unit, k-step) sequence of a workgroup is ONE stream; operand slices arrive by
+//     global_load_lds into a 3-deep LDS ring that runs two k-steps ahead ACROSS unit boundaries, so only
+//     the first unit of a workgroup ever waits for a cold load;
+//   * software-pipelined epilogue: two accumulator sets.  While the MFMAs of unit i+1 fill one set, the
+//     requant arithmetic of unit i drains the other in the same instruction stream, one 32 x 32 sub-tile
+//     per k-step — VALU work issued between MFMAs instead of after them (tools/ubench/overlap.hip);
+//   * the bias is the MFMA C operand of a unit's first k-step (no add in the epilogue); the per-channel
+//     multipliers c = m * 2^-e come precomputed from the linear plan (ivit_linear_plan_create), which
+//     also PROVES per channel, from sum_k |W[n,k]|, that rne((acc + bias) * c) may be taken as the low
+//     dword of fma(double(z), c, 1.5 * 2^52): one v_cvt_f64_i32 + one v_fma_f64 per output element;
+//   * every other vector-memory instruction of the epilogue (output stores, the residual loads) is issued
+//     right BEFORE a k-step's operand DMA, so the counted `s_waitcnt vmcnt(n)` of the next step retires it
+//     together with the operands it has to wait for anyway and never drains the ring (n = the DMA
+//     instructions of the newest step: loads return in order).
+//
+// LDS (ASTAT): panel 96 KB | weight ring 3 x 8 KB | staged output tile 34 KB (int8: 256 x 128; int16: two
+// 64-channel halves) | per-unit constants 2 x 1.5 KB (double-buffered: unit i's multipliers are still in
+// use while unit i+1's bias is loaded) = 157 KB.  Streaming: ring 3 x 16 KB | 17 KB | 3 KB = 68 KB.
+//
+// Arithmetic (bit-exact restatement of quant_utils.py:229-231, see ivit_gemm2.h): swapped MFMA operands
+// (weights = "A"), so a lane holds one token and 4 consecutive channels per register quad.
+// Ablation (env IVIT_GEMM3_DBG, timing only, results invalid): 1 = no operand DMA after the first unit,
+// 2 = no LDS fragment reads / MFMAs, 4 = no epilogue arithmetic, 8 = no output stores (RQ8 epilogue).
+#pragma once
+#include "ivit_gemm2.h"
+
+// ablation mask, compile time only (a run-time test would split every k-step into several basic blocks and
+// forbid the MFMA / VALU interleaving the kernels are built around): build with -DG3_DBG=<mask> into a scratch
+// library and point IVIT_LIB at it.  1 = no operand DMA after the first unit, 2 = no LDS fragment reads / MFMAs,
+// 4 = no epilogue arithmetic, 8 = no output stores.  Results are invalid, timing only.
+#ifndef G3_DBG
+#define G3_DBG 0
+#endif
+#define G3_NS 3
+#define G3_STG_LD 136
+#define G3_CONST_BYTES 1536
+#define G3_MAGIC 6755399441055744.0
+#define G3_MAXNK_ASTAT 6                 // panel slices that fit: K <= 384
+
+template <bool ASTAT> struct G3Cfg {
+    static constexpr int BM = ASTAT ? 256 : 128;
+    static constexpr int NT = BM * 2;                                  // threads: one wave per 64 x 64 sub-tile
+    static constexpr int PANEL = ASTAT ? G3_MAXNK_ASTAT * 16384 : 0;    // stationary A slices [nk][256 x 64]
+    static constexpr int STAGE = ASTAT ? 8192 : 16384;                  // ring stage: W slice (+ A slice when streaming)
+    static constexpr int RING = G3_NS * STAGE;
+    static constexpr int STG = BM * G3_STG_LD;
+    static constexpr int SMEM = PANEL + RING + STG + 2 * G3_CONST_BYTES;
+};
+
+struct G3Tile {
+    int row0, col0;   // first token / channel of the tile
+    int par;          // constants buffer of this tile
+};
+
+// ---- per-tile constants -> LDS by DMA: c[128] (wave 0), bias[0..63] (wave 1), bias[64..127] (wave 2)
+__device__ __forceinline__ void g3_issue_consts(const GemmArgs &p, int col0, char *cst, int wave, int lane) {
+    if (wave == 0) {
+        int ch = min(col0 + 2 * lane, p.N - 2);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(p.cq + ch),
+                                         (__attribute__((address_space(3))) void *)cst, 16, 0, 0);
+    } else if (wave < 3) {
+        int ch = min(col0 + (wave - 1) * 64 + lane, p.N - 1);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(p.bias + ch),
+                                         (__attribute__((address_space(3))) void *)(cst + 1024 + (wave - 1) * 256), 4, 0, 0);
+    }
+}
+
+// ---- requant of one 32 x 32 accumulator sub-tile (bias already inside) -> staged tile
+// OUT8: int8 staging [token][128 channels]; else int16 staging [token][2 x 32 channels] (one 64-channel half)
+template <bool OUT8, bool FMA>
+__device__ __forceinline__ void g3_requant_subtile(const v16i &acc, const char *cst, char *stg, int ml, int nl0,
+                                                   int st_off) {
+    const double *cbase = reinterpret_cast<const double *>(cst);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const double *cp = cbase + nl0 + g * 8;
+        int o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int z = acc[g * 4 + e];
+            const double t = FMA ? __builtin_fma((double)z, cp[e], G3_MAGIC) : ((double)z * cp[e] + G3_MAGIC);
+            const int v = __double2loint(t);
+            o[e] = OUT8 ? min(max(v, -128), 127) : min(max(v, -32768), 32767);
+        }
+        if (OUT8) {
+            unsigned w01 = __builtin_amdgcn_perm((unsigned)o[1], (unsigned)o[0], 0x0c0c0400u);
+            unsigned w23 = __builtin_amdgcn_perm((unsigned)o[3], (unsigned)o[2], 0x0c0c0400u);
+            *reinterpret_cast<unsigned *>(stg + ml * G3_STG_LD + st_off + g * 8) = __builtin_amdgcn_perm(w23, w01, 0x05040100u);
+        } else {
+            v2i w = {(int)__builtin_amdgcn_perm((unsigned)o[1], (unsigned)o[0], 0x05040100u),
+                     (int)__builtin_amdgcn_perm((unsigned)o[3], (unsigned)o[2], 0x05040100u)};
+            *reinterpret_cast<v2i *>(stg + ml * G3_STG_LD + st_off + g * 16) = w;
+        }
+    }
+}
+
+__device__ __forceinline__ int g3_div(int x, int d, float rcp) {
+    int q = (int)((float)x * rcp);
+    const int r = x - q * d;
+    if (r < 0) --q;
+    else if (r >= d) ++q;
+    return q;
+}
+
+__device__ __forceinline__ v4i g3_stg_read16(const char *sp) {
+    v2i lo = *reinterpret_cast<const v2i *>(sp), hi = *reinterpret_cast<const v2i *>(sp + 8);
+    return v4i{lo[0], lo[1], hi[0], hi[1]};
+}
+
+// plain 16-byte global load the compiler's wait-count model does not see (it would drain the DMA ring with
+// vmcnt(0) at the first use); the value is complete after the NEXT k-step's counted wait (issue order below)
+__device__ __forceinline__ v4i g3_load16_async(const void *ptr) {
+    v4i v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+    return v;
+}
+
+// DMA of one 64-column slice of a 256-row A panel (ASTAT): 16 KB, two 16-byte pieces per thread, into the
+// XOR-swizzled [row][64] image the fragment reads expect (same image as g2_issue's)
+__device__ __forceinline__ void g3_issue_a256(const int8_t *A, int lda, int M, int row0, int k0, char *dst, int tid) {
+    const int wave = tid >> 6;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int id = tid + i * 512, row = id >> 2, pos = id & 3;
+        const int c = pos ^ ((row >> 2) & 3);
+        const int grow = min(row0 + row, M - 1);
+        const int8_t *src = A + (long long)grow * lda + k0 + c * 16;
+        const unsigned loff = __builtin_amdgcn_readfirstlane((unsigned)(i * 8192 + wave * 1024));
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(dst + loff), 16, 0, 0);
+    }
+}
+// one 64-column slice of a 128-channel weight tile: 8 KB, one piece per thread of a 512-thread workgroup
+__device__ __forceinline__ void g3_issue_w128(const int8_t *B, int ldb, int N, int col0, int k0, char *dst, int tid) {
+    const int wave = tid >> 6;
+    const int row = tid >> 2, pos = tid & 3;
+    const int c = pos ^ ((row >> 2) & 3);
+    const int grow = min(col0 + row, N - 1);
+    const int8_t *src = B + (long long)grow * ldb + k0 + c * 16;
+    const unsigned loff = __builtin_amdgcn_readfirstlane((unsigned)(wave * 1024));
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                     (__attribute__((address_space(3))) void *)(dst + loff), 16, 0, 0);
+}
+
+template <int EPI, bool FMA, bool ASTAT>
+__global__ __launch_bounds__(G3Cfg<ASTAT>::NT, 2) void gemm_ps_kernel(GemmArgs p) {
+    using Cf = G3Cfg<ASTAT>;
+    constexpr int NT = Cf::NT, BM = Cf::BM, BMSH = ASTAT ? 8 : 7;
+    __shared__ __attribute__((aligned(16))) char smem[Cf::SMEM];
+    char *const ring = smem + Cf::PANEL;
+    char *const stg = ring + Cf::RING;
+    char *const cst0 = stg + Cf::STG;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5;
+    constexpr bool OUT8 = (EPI == EPI_RQ8_CH || EPI == EPI_QKV);
+    constexpr bool RES = (EPI == EPI_RQ16_CH_RES);
+
+    // ---- this workgroup's units.  Unit u = (row block u / tiles_n, channel tile u % tiles_n).
+    // ASTAT: one contiguous range [u_first, u_end), step 1 (consecutive units share the stationary panel);
+    //        ranges are handed out so that the workgroups of one XCD (b % 8) hold neighbouring ranges.
+    // streaming: the unit space is cut into one contiguous range per XCD; the workgroups of an XCD take the
+    //        units of its range round-robin (units that share an A panel run at the same time on one L2).
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const long long nunits = (long long)((p.M + BM - 1) >> BMSH) * p.tiles_n;
+    int u_step, u_end, u_load;
+    if (ASTAT) {
+        const int r = (nwg & 7) == 0 ? (bid & 7) * (nwg >> 3) + (bid >> 3) : bid;
+        u_step = 1;
+        u_load = (int)(nunits * r / nwg);
+        u_end = (int)(nunits * (r + 1) / nwg);
+    } else {
+        const int parts = nwg < 8 ? nwg : 8;
+        const int part = bid % parts, li = bid / parts;
+        u_step = (nwg - part + parts - 1) / parts;
+        u_end = (int)(nunits * (part + 1) / parts);
+        u_load = (int)(nunits * part / parts) + li;
+    }
+    if (u_load >= u_end) return;
+    const int u_first = u_load;
+    const int nk = p.K >> 6;
+
+    const int8_t *A = reinterpret_cast<const int8_t *>(p.A);
+    const int8_t *B = p.B;
+
+    // ---- load cursor (runs two k-steps ahead of the MFMAs, across unit boundaries)
+    int l_kt = 0, l_slot = 0, l_par = 0;
+    int l_tm = u_load / p.tiles_n, l_tn = u_load - l_tm * p.tiles_n;
+    bool l_need_a = true;          // ASTAT: this unit brings its panel's slices along
+    int infl = 0;                  // DMA instructions per thread of the most recent issue (0: stream exhausted)
+    auto issue_next = [&]() __attribute__((always_inline)) {
+        if (u_load >= u_end) { infl = 0; return; }
+        const int row0 = l_tm << BMSH, col0 = l_tn << 7;
+        if (l_kt == 0) g3_issue_consts(p, col0, cst0 + l_par * G3_CONST_BYTES, wave, lane);
+        const bool skip = (G3_DBG & 1) && u_load != u_first;     // ablation: no operand traffic after the first unit
+        if (ASTAT) {
+            if (l_need_a) {
+                if (!skip) g3_issue_a256(A, p.lda, p.M, row0, l_kt * G2_BK, smem + l_kt * 16384, tid);
+                infl = 3;
+            } else {
+                infl = 1;
+            }
+            if (!skip) g3_issue_w128(B, p.ldb, p.N, col0, l_kt * G2_BK, ring + l_slot * Cf::STAGE, tid);
+        } else {
+            if (!skip) g2_issue<128>(A, B, p.lda, p.ldb, p.M, p.N, row0, col0, l_kt * G2_BK, ring + l_slot * Cf::STAGE, tid);
+            infl = 4;
+        }
+        if (skip) infl = 0;
+        l_slot = (l_slot == G3_NS - 1) ? 0 : l_slot + 1;
+        if (++l_kt == nk) {
+            l_kt = 0;
+            u_load += u_step;
+            l_par ^= 1;
+            if (ASTAT) {
+                l_need_a = false;
+                if (++l_tn == p.tiles_n) { l_tn = 0; ++l_tm; l_need_a = true; }
+            } else {
+                l_tm = u_load / p.tiles_n;
+                l_tn = u_load - l_tm * p.tiles_n;
+            }
+        }
+    };
+    issue_next();
+    issue_next();
+
+    int c_slot = 0;                                         // ring slot of the k-step being multiplied
+    const int ml0 = wm * 64 + (lane & 31);                  // token of this lane inside the unit (+32 for i = 1)
+
+    const double cm = p.dy_main.m * p.dy_main.r, cr = p.dy_res.m * p.dy_res.r;
+    const float rcpT = 1.0f / (float)(p.T > 0 ? p.T : 1), rcpD = 1.0f / (float)(p.D > 0 ? p.D : 1),
+                rcpdh = 1.0f / (float)(p.dh > 0 ? p.dh : 1);
+
+    // ------------------------------------------------------------------------------------------------
+    // one unit: K loop of `cur` into accC (HAS_CUR) with the epilogue of `prev` out of accP (HAS_PREV)
+    // spread over the first k-steps.  All branches inside are on template parameters or peeled step
+    // numbers: the MFMA + epilogue part of a k-step is ONE basic block, so the scheduler interleaves them.
+    auto tile_body = [&](auto has_cur_t, auto has_prev_t, v16i(&accC)[2][2], v16i(&accP)[2][2], const G3Tile cur,
+                         const G3Tile prev) __attribute__((always_inline)) {
+        constexpr bool HAS_CUR = decltype(has_cur_t)::value, HAS_PREV = decltype(has_prev_t)::value;
+        const char *pcst = cst0 + prev.par * G3_CONST_BYTES;
+        const char *ccst = cst0 + cur.par * G3_CONST_BYTES;
+        v4i hold[4];      // 16-bit epilogues: finished 16-byte output pieces waiting for their store slot
+        v4i resv[4];      // residual pieces in flight
+        (void)hold; (void)resv;
+
+        // ---- epilogue pieces: thread -> (row, 16-byte piece) of the staged tile, 4 pieces per thread
+        auto out8_store = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (EPI == EPI_RQ8_CH) {
+                    const int id = tid + i * NT, row = id >> 3, c = id & 7;
+                    const int grow = prev.row0 + row, gcol = prev.col0 + c * 16;
+                    const v4i v = g3_stg_read16(stg + row * G3_STG_LD + c * 16);
+                    if (grow < p.M && gcol < p.N && !(G3_DBG & 8))
+                        *reinterpret_cast<v4i *>(reinterpret_cast<int8_t *>(p.out) + (long long)grow * p.ldc + gcol) = v;
+                } else {
+                    // rows-fastest: a wave covers 64 consecutive tokens of one 16-channel piece
+                    const int id = tid + i * NT, row = id & (BM - 1), c = id >> BMSH;
+                    const int grow = prev.row0 + row, gcol = prev.col0 + c * 16;
+                    const v4i v = g3_stg_read16(stg + row * G3_STG_LD + c * 16);
+                    if (grow < p.M && gcol < p.N) {
+                        // float-reciprocal quotients with one correction step (operands < 2^23)
+                        const int which = g3_div(gcol, p.D, rcpD), within = gcol - which * p.D;
+                        const int head = g3_div(within, p.dh, rcpdh), d0 = within - head * p.dh;
+                        const int b = g3_div(grow, p.T, rcpT), t = grow - b * p.T;
+                        const long long bh = (long long)b * p.H + head;
+                        if (which < 2) {
+                            int8_t *dst = (which == 0 ? p.q : p.k) + (bh * p.T + t) * p.dh + d0;
+                            *reinterpret_cast<v4i *>(dst) = v;
+                        } else {
+                            int8_t *dst = p.vt + (bh * p.dh + d0) * p.ldv + t;
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) dst[(long long)e * p.ldv] = (int8_t)(v[e >> 2] >> (8 * (e & 3)));
+                        }
+                    }
+                }
+            }
+        };
+        // 16-bit halves: piece id -> row, 64-channel segment (wn) and 8-channel group inside the half
+        auto h16_addr = [&](int i, int j, int &row, int &sc, long long &goff, bool &ok) __attribute__((always_inline)) {
+            const int id = tid + i * NT;
+            row = id >> 3;
+            const int c = id & 7;
+            sc = c * 16;                                                  // byte offset in the staged row
+            const int grow = prev.row0 + row, gcol = prev.col0 + (c >> 2) * 64 + j * 32 + (c & 3) * 8;
+            ok = grow < p.M && gcol < p.N;
+            goff = (long long)grow * p.ldc + gcol;
+        };
+        auto res_issue = [&](int j) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int row, sc; long long goff; bool ok;
+                h16_addr(i, j, row, sc, goff, ok);
+                const long long safe = ok ? goff : 0;
+                resv[i] = g3_load16_async(p.residual + safe);
+            }
+        };
+        auto h16_finish = [&](int j) __attribute__((always_inline)) {     // staged half -> (residual requant-add) -> hold[]
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int row, sc; long long goff; bool ok;
+                h16_addr(i, j, row, sc, goff, ok);
+                v4i v = g3_stg_read16(stg + row * G3_STG_LD + sc);
+                if (RES) {
+                    const v4i rs = resv[i];
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const int t0 = (int)(short)(v[w] & 0xffff), t1 = v[w] >> 16;
+                        const int r0 = (int)(short)(rs[w] & 0xffff), r1 = rs[w] >> 16;
+                        int o0 = rq_fast(r0, cr) + rq_fast(t0, cm);
+                        int o1 = rq_fast(r1, cr) + rq_fast(t1, cm);
+                        o0 = min(max(o0, -32768), 32767);
+                        o1 = min(max(o1, -32768), 32767);
+                        v[w] = (o0 & 0xffff) | (o1 << 16);
+                    }
+                }
+                hold[i] = v;
+            }
+        };
+        auto h16_store = [&](int j) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int row, sc; long long goff; bool ok;
+                h16_addr(i, j, row, sc, goff, ok);
+                if (ok) *reinterpret_cast<v4i *>(reinterpret_cast<int16_t *>(p.out) + goff) = hold[i];
+            }
+        };
+        // vector-memory work of epilogue step CH, issued BEFORE the step's operand DMA
+        auto epi_pre = [&](auto ch_t) __attribute__((always_inline)) {
+            constexpr int CH = decltype(ch_t)::value;
+            if (!HAS_PREV) return;
+            if (OUT8) {
+                if (CH == 4) out8_store();
+            } else {
+                if (CH == 0 && RES) res_issue(0);
+                if (CH == 2) { h16_store(0); if (RES) res_issue(1); }
+                if (CH == 4) h16_store(1);
+            }
+        };
+        // arithmetic of epilogue step CH (interleaves with the step's MFMAs)
+        auto epi_main = [&](auto ch_t) __attribute__((always_inline)) {
+            constexpr int CH = decltype(ch_t)::value;
+            if (!HAS_PREV) return;
+            if constexpr (OUT8) {
+                if constexpr (CH < 4) {
+                    constexpr int i = CH & 1, j = CH >> 1;
+                    g3_requant_subtile<true, FMA>(accP[i][j], pcst, stg, ml0 + i * 32, wn * 64 + j * 32 + half * 4,
+                                                  wn * 64 + j * 32 + half * 4);
+                }
+            } else {
+                if constexpr (CH == 0 || CH == 2) {
+                    constexpr int j = CH >> 1;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        g3_requant_subtile<false, FMA>(accP[i][j], pcst, stg, ml0 + i * 32, wn * 64 + j * 32 + half * 4,
+                                                       wn * 64 + half * 8);
+                }
+                if (CH == 1) h16_finish(0);
+                if (CH == 3) h16_finish(1);
+            }
+        };
+
+        // ---- one k-step ---------------------------------------------------------------------------
+        auto kstep = [&](auto ch_t, const int kt) __attribute__((always_inline)) {
+            constexpr int CH = decltype(ch_t)::value;      // epilogue step (6 = none)
+            // operands of THIS step complete; the newest step's `infl` DMA instructions stay in flight
+            if (!HAS_CUR || infl == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            else if (!ASTAT) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            else if (infl == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+            // lgkmcnt(0): a raw s_barrier does not wait for this wave's own LDS reads / staging writes
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            epi_pre(ch_t);
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (HAS_CUR) {
+                issue_next();
+                asm volatile("" ::: "memory");
+            }
+            if (HAS_CUR && !(G3_DBG & 2)) {
+                const char *sB = ring + c_slot * Cf::STAGE + (ASTAT ? 0 : 8192);
+                const char *sA = ASTAT ? smem + kt * 16384 : ring + c_slot * Cf::STAGE;
+                v4i a[2], b[2];
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int chunk = kk * 2 + half;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        a[i] = *reinterpret_cast<const v4i *>(sA + lds_off(wm * 64 + i * 32 + (lane & 31), chunk));
+                        b[i] = *reinterpret_cast<const v4i *>(sB + lds_off(wn * 64 + i * 32 + (lane & 31), chunk));
+                    }
+                    if (CH == 0 && kk == 0) {
+                        // first MFMA of the unit: C operand = bias (lane: channels 32j + 8g + 4*half + e)
+                        const int *bp = reinterpret_cast<const int *>(ccst + 1024) + wn * 64 + half * 4;
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            v16i init;
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const v4i bv = *reinterpret_cast<const v4i *>(bp + j * 32 + g * 8);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) init[g * 4 + e] = bv[e];
+                            }
+#pragma unroll
+                            for (int i = 0; i < 2; ++i)
+                                accC[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b[j], a[i], init, 0, 0, 0);
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j)
+                                accC[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b[j], a[i], accC[i][j], 0, 0, 0);
+                    }
+                }
+            }
+            if (HAS_CUR) c_slot = (c_slot == G3_NS - 1) ? 0 : c_slot + 1;
+            if (!(G3_DBG & 4)) epi_main(ch_t);
+        };
+        kstep(std::integral_constant<int, 0>{}, 0);
+        kstep(std::integral_constant<int, 1>{}, 1);
+        kstep(std::integral_constant<int, 2>{}, 2);
+        kstep(std::integral_constant<int, 3>{}, 3);
+        kstep(std::integral_constant<int, 4>{}, 4);
+        if (HAS_CUR) {
+            for (int kt = 5; kt < nk; ++kt) kstep(std::integral_constant<int, 6>{}, kt);
+        }
+    };
+
+    // ---- the unit stream, two accumulator sets alternating
+    v16i acc0[2][2], acc1[2][2];
+    int u_cur = u_first;
+    auto locate = [&](int u, G3Tile &t) __attribute__((always_inline)) {
+        const int tm = u / p.tiles_n;
+        t.row0 = tm << BMSH;
+        t.col0 = (u - tm * p.tiles_n) << 7;
+    };
+    G3Tile cur{0, 0, 0}, prev{0, 0, 0};
+    locate(u_cur, cur);
+    auto advance = [&]() __attribute__((always_inline)) {
+        prev = cur;
+        u_cur += u_step;
+        locate(u_cur, cur);
+        cur.par ^= 1;
+        return u_cur < u_end;
+    };
+    const std::true_type T{};
+    const std::false_type F{};
+    tile_body(T, F, acc0, acc1, cur, prev);
+    for (;;) {
+        if (!advance()) { tile_body(F, T, acc1, acc0, cur, prev); break; }
+        tile_body(T, T, acc1, acc0, cur, prev);
+        if (!advance()) { tile_body(F, T, acc0, acc1, cur, prev); break; }
+        tile_body(T, T, acc0, acc1, cur, prev);
+    }
+}
+
+// =====================================================================================================
+// gemm_as_kernel — A-stationary, K = 384 (6 k-steps): qkv, proj, fc1 of the D = 384 models.
+//
+// Measured on the first A-stationary version (3-deep weight ring, LDS-staged epilogue; IVIT_GEMM3_DBG):
+// with MFMAs, epilogue and stores all switched off, fc1's loop of {wait for the weight slice, barrier,
+// request the slice two steps ahead} still took 25 us — a global_load_lds takes ~0.85 us from issue to
+// landing, so a ring that runs two steps ahead makes every k-step last half that latency no matter how
+// little it computes.  This kernel spends the LDS on prefetch depth instead of on a staged output tile:
+//
+//   LDS: panel 6 x 16 KB (stationary A slices) | weight ring 6 x 8 KB (one whole unit, requested two PAIRS of
+//        k-steps ahead: one barrier per pair; ring slot == k-step index) | constants 3 x 1.5 KB                 = 148.5 KB
+//        (unit i-1's multipliers are in use until step 5 of unit i, whose step 4 already requests unit i+1's)
+//   * epilogue without LDS: a lane's 4 packed dwords of a 32 x 32 sub-tile (4-channel runs at 8g + 4*half)
+//     become 16 consecutive channels of one token with two v_permlane32_swap — straight 16-byte stores
+//     (int8) or 2 x 16 bytes (int16); the residual is loaded in the same layout, so the identity
+//     requant-add happens in registers;
+//   * exact wait counts: vector-memory instructions retire in issue order (loads AND stores: the compiler's
+//     own gfx9 wait-count model relies on it), so "the slice of step s has landed" is
+//     `s_waitcnt vmcnt(#instructions issued after it)`.  Every such instruction is issued unconditionally
+//     (lanes outside the matrix store to a scratch line), the running count lives in SGPRs, and the wait
+//     is picked from a jump table of immediates.  Stores and residual loads therefore never hold up the
+//     operand stream, wherever they are issued.
+#define GA_NK 6
+#define GA_PANEL (GA_NK * 16384)
+#define GA_WSTAGE 8192
+#define GA_RING (GA_NK * GA_WSTAGE)
+#define GA_SMEM (GA_PANEL + GA_RING + 3 * G3_CONST_BYTES)
+// timeline instrumentation (compile time, -DG3_TRACE=1 into a scratch library): wave w of workgroup 0 stamps
+// s_memtime at four points of every k-step of its units 2..4 into LDS and dumps them behind the plan's store
+// scratch (read back with ivit_debug_plan_scratch).  Points: 0 after the barrier, 1 after the DMA requests,
+// 2 after the MFMA + epilogue block, 3 after the counted wait (before the next barrier).
+#ifndef G3_TRACE
+#define G3_TRACE 0
+#endif
+#define GA_TRACE_BYTES (G3_TRACE ? 8 * 3 * 6 * 4 * 8 : 0)
+
+// wait until at most n (uniform, SGPR) vector-memory instructions of this wave are outstanding, and for all LDS
+// traffic.  s_waitcnt only takes an immediate, so the wait is an indexed jump into a table of 48 eight-byte
+// {s_waitcnt vmcnt(k) lgkmcnt(0); s_branch end} entries: five scalar instructions and one jump.  (A C++ switch
+// over the same cases compiled into a tree of ~40 scalar branches — 900 cycles per k-step, measured.)
+#define GA_W1(k) "s_waitcnt vmcnt(" #k ") lgkmcnt(0)\n\ts_branch .Lgaw%=\n\t"
+#define GA_W8(a, b, c, d, e, f, g, h) GA_W1(a) GA_W1(b) GA_W1(c) GA_W1(d) GA_W1(e) GA_W1(f) GA_W1(g) GA_W1(h)
+__device__ __forceinline__ void ga_wait_vm(int n) {
+    n = n < 0 ? 0 : (n > 47 ? 47 : n);
+    const int off = __builtin_amdgcn_readfirstlane(n * 8 + 12);   // table starts 12 bytes after the s_getpc result
+    asm volatile(
+        "s_getpc_b64 vcc\n\t"
+        "s_add_u32 vcc_lo, vcc_lo, %0\n\t"
+        "s_addc_u32 vcc_hi, vcc_hi, 0\n\t"
+        "s_setpc_b64 vcc\n\t"
+        GA_W8(0, 1, 2, 3, 4, 5, 6, 7) GA_W8(8, 9, 10, 11, 12, 13, 14, 15) GA_W8(16, 17, 18, 19, 20, 21, 22, 23)
+        GA_W8(24, 25, 26, 27, 28, 29, 30, 31) GA_W8(32, 33, 34, 35, 36, 37, 38, 39) GA_W8(40, 41, 42, 43, 44, 45, 46, 47)
+        ".Lgaw%=:\n\t"
+        :: "s"(off) : "vcc", "scc", "memory");
+}
+
+// swap the upper-half lanes of `a` with the lower-half lanes of `b`
+__device__ __forceinline__ void ga_swap32(int &a, int &b) {
+    typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+    const v2u_t r = __builtin_amdgcn_permlane32_swap((unsigned)a, (unsigned)b, false, false);
+    a = (int)r[0];
+    b = (int)r[1];
+}
+
+template <int EPI, bool FMA>
+__global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[GA_SMEM + GA_TRACE_BYTES];
+    char *const ring = smem + GA_PANEL;
+    char *const cst0 = ring + GA_RING;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5;
+    constexpr bool OUT8 = (EPI == EPI_RQ8_CH || EPI == EPI_QKV);
+    constexpr bool RES = (EPI == EPI_RQ16_CH_RES);
+
+    // ---- this workgroup's contiguous unit range; unit u = (256-token panel u / tiles_n, 128-channel tile u % tiles_n).
+    // Ranges are handed out so that the workgroups of one XCD (b % 8) hold neighbouring ranges.
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const long long nunits = (long long)((p.M + 255) >> 8) * p.tiles_n;
+    const int rr = (nwg & 7) == 0 ? (bid & 7) * (nwg >> 3) + (bid >> 3) : bid;
+    const int u_first = (int)(nunits * rr / nwg), u_end = (int)(nunits * (rr + 1) / nwg);
+    if (u_first >= u_end) return;
+
+    const int8_t *A = reinterpret_cast<const int8_t *>(p.A);
+    const int8_t *B = p.B;
+    char *const dummy = reinterpret_cast<char *>(p.dummy) + lane * 16;    // where lanes outside the matrix store
+
+    // ---- vector-memory bookkeeping (all uniform): `issued` counts this wave's VMEM instructions,
+    // mark[k] = count right after the slices of k-step k (ring slot k) were requested
+    int issued = 0, mark[GA_NK] = {0, 0, 0, 0, 0, 0}, mark_res[4] = {0, 0, 0, 0}, mark_cst = 0;
+
+    // ---- load cursor: two pairs of k-steps ahead of the MFMAs, across unit boundaries
+    int u_load = u_first, l_kt = 0;
+    int l_tm = u_load / p.tiles_n, l_tn = u_load - l_tm * p.tiles_n;
+    int l_need_a = 1;             // this unit brings its panel's slices along (int: a by-reference bool lands in scratch)
+    auto issue_next = [&](auto slot_t) __attribute__((always_inline)) {
+        constexpr int SLOT = decltype(slot_t)::value;           // == l_kt (the stream advances one k-step per call)
+        if (u_load >= u_end) return;
+        const bool skip = (G3_DBG & 1) && u_load != u_first;     // ablation: no operand traffic after the first unit
+        if (l_need_a) {
+            if (!skip) { g3_issue_a256(A, p.lda, p.M, l_tm << 8, SLOT * G2_BK, smem + SLOT * 16384, tid); issued += 2; }
+        }
+        if (!skip) { g3_issue_w128(B, p.ldb, p.N, l_tn << 7, SLOT * G2_BK, ring + SLOT * GA_WSTAGE, tid); issued += 1; }
+        mark[SLOT] = issued;
+        if (++l_kt == GA_NK) {
+            l_kt = 0;
+            ++u_load;
+            l_need_a = 0;
+            if (++l_tn == p.tiles_n) { l_tn = 0; ++l_tm; l_need_a = 1; }
+        }
+    };
+    auto issue_consts = [&](int col0, int par) __attribute__((always_inline)) {
+        g3_issue_consts(p, col0, cst0 + par * G3_CONST_BYTES, wave, lane);
+        if (wave < 3) issued += 1;
+        mark_cst = issued;
+    };
+    issue_consts(l_tn << 7, 0);
+    issue_next(std::integral_constant<int, 0>{});
+    issue_next(std::integral_constant<int, 1>{});
+    issue_next(std::integral_constant<int, 2>{});
+    issue_next(std::integral_constant<int, 3>{});
+
+    const double cm = p.dy_main.m * p.dy_main.r, cr = p.dy_res.m * p.dy_res.r;
+    const float rcpT = 1.0f / (float)(p.T > 0 ? p.T : 1);
+    int tr_unit = -2;     // trace: index of the current unit relative to the first traced one
+    auto trace = [&](int kt, int pt) __attribute__((always_inline)) {
+        if (G3_TRACE && bid == 0 && lane == 0 && tr_unit >= 0 && tr_unit < 3) {
+            unsigned long long *tb = reinterpret_cast<unsigned long long *>(smem + GA_SMEM);
+            tb[(wave * 3 + tr_unit) * 24 + kt * 4 + pt] = __builtin_readcyclecounter();
+        }
+    };
+    v4i resv[8];          // residual pieces in flight / waiting for their sub-tile's epilogue (two k-steps later): [(j*2 + i)*2 + piece]
+    (void)resv;
+
+    // token row / channel column of this lane's 16-channel run in sub-tile (i, j) of a unit
+    auto sub_row = [&](const G3Tile &t, int i) __attribute__((always_inline)) { return t.row0 + wm * 64 + i * 32 + (lane & 31); };
+    auto sub_col = [&](const G3Tile &t, int j) __attribute__((always_inline)) { return t.col0 + wn * 64 + j * 32 + half * 16; };
+
+    auto tile_body = [&](auto has_cur_t, auto has_prev_t, v16i(&accC)[2][2], v16i(&accP)[2][2], const G3Tile cur,
+                         const G3Tile prev, const bool has_next, const int next_col0) __attribute__((always_inline)) {
+        constexpr bool HAS_CUR = decltype(has_cur_t)::value, HAS_PREV = decltype(has_prev_t)::value;
+        const double *pc = reinterpret_cast<const double *>(cst0 + prev.par * G3_CONST_BYTES);
+        const char *ccst = cst0 + cur.par * G3_CONST_BYTES;
+
+        // ---- epilogue of sub-tile (i, j) of `prev`: requant -> pack -> half-wave exchange -> store
+        auto epi_sub = [&](auto c_t) __attribute__((always_inline)) {
+            constexpr int C = decltype(c_t)::value, i = C & 1, j = C >> 1;
+            const v16i &acc = accP[i][j];
+            const int grow = sub_row(prev, i), gcol = sub_col(prev, j);
+            const bool ok = grow < p.M && gcol < p.N;
+            const int nl0 = wn * 64 + j * 32 + half * 4;
+            auto rq = [&](int g, int e) __attribute__((always_inline)) {
+                const int z = acc[g * 4 + e];
+                const double c = pc[nl0 + g * 8 + e];
+                const double t = FMA ? __builtin_fma((double)z, c, G3_MAGIC) : ((double)z * c + G3_MAGIC);
+                const int v = __double2loint(t);
+                return OUT8 ? min(max(v, -128), 127) : min(max(v, -32768), 32767);
+            };
+            if constexpr (OUT8) {
+                int d[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int o0 = rq(g, 0), o1 = rq(g, 1), o2 = rq(g, 2), o3 = rq(g, 3);
+                    const unsigned w01 = __builtin_amdgcn_perm((unsigned)o1, (unsigned)o0, 0x0c0c0400u);
+                    const unsigned w23 = __builtin_amdgcn_perm((unsigned)o3, (unsigned)o2, 0x0c0c0400u);
+                    d[g] = (int)__builtin_amdgcn_perm(w23, w01, 0x05040100u);
+                }
+                // lower half-wave: channels 0..15 of the token = {h0.d0, h1.d0, h0.d1, h1.d1}; upper: 16..31
+                ga_swap32(d[0], d[2]);
+                ga_swap32(d[1], d[3]);
+                const v4i v = {d[0], d[2], d[1], d[3]};
+                if (G3_DBG & 8) return;
+                if constexpr (EPI == EPI_RQ8_CH) {
+                    char *dst = ok ? reinterpret_cast<char *>(p.out) + (long long)grow * p.ldc + gcol : dummy;
+                    *reinterpret_cast<v4i *>(dst) = v;
+                    issued += 1;
+                } else {
+                    // q / k: [b, head, t, dh] — 16 channels of one head; v^T: [b, head, dh, ldv] byte scatter.
+                    // The 128-column unit lies inside one of q / k / v and the 32-column group inside one head
+                    // (D % 128 == 0, dh % 32 == 0: checked by the host), so which / head are uniform.
+                    const int ucol = prev.col0 + wn * 64 + j * 32;
+                    const int which = ucol / p.D, within = ucol - which * p.D;
+                    const int head = within / p.dh, d0 = within - head * p.dh + half * 16;
+                    const int gr = ok ? grow : 0;
+                    const int b = g3_div(gr, p.T, rcpT), t = gr - b * p.T;
+                    const long long bh = (long long)b * p.H + head;
+                    if (which < 2) {
+                        char *dst = reinterpret_cast<char *>(which == 0 ? p.q : p.k) + (bh * p.T + t) * p.dh + d0;
+                        *reinterpret_cast<v4i *>(ok ? dst : dummy) = v;
+                        issued += 1;
+                    } else {
+                        char *dst = reinterpret_cast<char *>(p.vt) + (bh * p.dh + d0) * p.ldv + t;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            char *d1 = ok ? dst + (long long)e * p.ldv : dummy;
+                            *d1 = (char)(v[e >> 2] >> (8 * (e & 3)));
+                        }
+                        issued += 16;
+                    }
+                }
+            } else {
+                // two independent 8-channel pieces per lane: piece h2 pairs the quads g = h2 and g = h2 + 2.
+                // lower half-wave: channels 8*h2 .. +7 = {h0.g(h2), h1.g(h2)}; upper half-wave: 16 + the same
+                char *dst = ok ? reinterpret_cast<char *>(p.out) + ((long long)grow * p.ldc + gcol) * 2 : dummy;
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    int w[2][2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int g = h2 + 2 * q;
+                        w[q][0] = (int)__builtin_amdgcn_perm((unsigned)rq(g, 1), (unsigned)rq(g, 0), 0x05040100u);
+                        w[q][1] = (int)__builtin_amdgcn_perm((unsigned)rq(g, 3), (unsigned)rq(g, 2), 0x05040100u);
+                    }
+                    ga_swap32(w[0][0], w[1][0]);
+                    ga_swap32(w[0][1], w[1][1]);
+                    v4i v = {w[0][0], w[0][1], w[1][0], w[1][1]};
+                    if constexpr (RES) {
+                        const v4i rs = resv[C * 2 + h2];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int t0 = (int)(short)(v[q] & 0xffff), t1 = v[q] >> 16;
+                            const int r0 = (int)(short)(rs[q] & 0xffff), r1 = rs[q] >> 16;
+                            int o0 = rq_fast(r0, cr) + rq_fast(t0, cm);
+                            int o1 = rq_fast(r1, cr) + rq_fast(t1, cm);
+                            o0 = min(max(o0, -32768), 32767);
+                            o1 = min(max(o1, -32768), 32767);
+                            v[q] = (o0 & 0xffff) | (o1 << 16);
+                        }
+                    }
+                    if (!(G3_DBG & 8)) {
+                        *reinterpret_cast<v4i *>(ok ? dst + h2 * 16 : dummy) = v;
+                        issued += 1;
+                    }
+                }
+            }
+        };
+
+        // residual of sub-tile C of unit `t`, in the epilogue's register layout; requested two k-steps before its
+        // epilogue step (8 registers per sub-tile in flight instead of 32 for the whole unit)
+        auto res_request = [&](auto c_t, const G3Tile &t) __attribute__((always_inline)) {
+            constexpr int C = decltype(c_t)::value;
+            const int grow = sub_row(t, C & 1), gcol = sub_col(t, C >> 1);
+            const bool ok = grow < p.M && gcol < p.N;
+            const char *src = ok ? reinterpret_cast<const char *>(p.residual) + ((long long)grow * p.ldc + gcol) * 2 : dummy;
+            resv[C * 2] = g3_load16_async(src);
+            resv[C * 2 + 1] = g3_load16_async(ok ? src + 16 : dummy);
+            issued += 2;
+            mark_res[C] = issued;
+        };
+
+        // MFMAs of k-step KT; `between` runs after the first half's MFMAs are issued (the DMA requests go there:
+        // a global_load_lds costs the issuing wave ~100+ cycles, which the matrix pipe spends on those MFMAs)
+        auto mma_step = [&](auto kt_t, auto between) __attribute__((always_inline)) {
+            constexpr int KT = decltype(kt_t)::value;
+            const char *sA = smem + KT * 16384;
+            const char *sB = ring + KT * GA_WSTAGE;
+            v4i a[2], b[2];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int chunk = kk * 2 + half;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    a[i] = *reinterpret_cast<const v4i *>(sA + lds_off(wm * 64 + i * 32 + (lane & 31), chunk));
+                    b[i] = *reinterpret_cast<const v4i *>(sB + lds_off(wn * 64 + i * 32 + (lane & 31), chunk));
+                }
+                if (KT == 0 && kk == 0) {
+                    // first MFMA of the unit: C operand = bias (lane: channels 32j + 8g + 4*half + e)
+                    const int *bp = reinterpret_cast<const int *>(ccst + 1024) + wn * 64 + half * 4;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        v16i init;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const v4i bv = *reinterpret_cast<const v4i *>(bp + j * 32 + g * 8);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) init[g * 4 + e] = bv[e];
+                        }
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+                            accC[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b[j], a[i], init, 0, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            accC[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b[j], a[i], accC[i][j], 0, 0, 0);
+                }
+                if (kk == 0) between();
+            }
+        };
+
+        // ---- one PAIR of k-steps (K0 = 2P, K1 = 2P + 1) behind one barrier.  The barrier publishes the slices of
+        // both steps (requested 4..5 steps ago) and frees the ring slots of the previous pair, which this pair's
+        // DMA requests refill for the pair after next.  Everything after the barrier is ONE basic block.
+        auto kpair = [&](auto p_t) __attribute__((always_inline)) {
+            constexpr int PP = decltype(p_t)::value, K0 = 2 * PP, K1 = K0 + 1;
+            // slices of K1 (requested after K0's) landed; the residual pieces of the sub-tiles whose epilogue runs in
+            // this pair (requested a pair ago); at pair 0 the unit's constants (requested at pair 2 of the previous unit)
+            {
+                int n = 1 << 20;
+                if (HAS_CUR) n = issued - mark[K1];
+                if (HAS_CUR && PP == 0) n = min(n, issued - mark_cst);
+                if (RES && HAS_PREV && PP >= 1) n = min(n, issued - mark_res[K1 - 2]);
+                if (HAS_CUR || (RES && HAS_PREV && PP >= 1)) ga_wait_vm(n);
+                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if constexpr (RES && HAS_PREV && PP >= 1)     // tie the residual registers to the wait
+                    asm volatile("" : "+v"(resv[(K0 - 2) * 2]), "+v"(resv[(K0 - 2) * 2 + 1]), "+v"(resv[(K1 - 2) * 2]),
+                                 "+v"(resv[(K1 - 2) * 2 + 1]));
+            }
+            // lgkmcnt(0) (inside ga_wait_vm): a raw s_barrier does not wait for this wave's own LDS reads
+            if (G3_TRACE && HAS_CUR) trace(PP == 0 ? 2 : PP - 1, 3);     // belongs to the previous pair's record
+            if (HAS_CUR) __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (G3_TRACE && HAS_CUR) { if (PP == 0) ++tr_unit; trace(PP, 0); }
+            auto requests = [&]() __attribute__((always_inline)) {
+                if (HAS_CUR) {
+                    issue_next(std::integral_constant<int, (K0 + 4) % GA_NK>{});
+                    issue_next(std::integral_constant<int, (K1 + 4) % GA_NK>{});
+                    if (PP == 2 && has_next) issue_consts(next_col0, cur.par == 2 ? 0 : cur.par + 1);
+                }
+                // residual of the sub-tiles finished in the NEXT pair: requested inside the same straight-line body
+                // (a value an asm load is still filling must not cross a loop edge: the register allocator may copy it)
+                if constexpr (RES && HAS_PREV && PP < 2) {
+                    res_request(std::integral_constant<int, K0>{}, prev);
+                    res_request(std::integral_constant<int, K1>{}, prev);
+                }
+                if (G3_TRACE && HAS_CUR) trace(PP, 1);
+            };
+            if (HAS_CUR && !(G3_DBG & 2)) {
+                mma_step(std::integral_constant<int, K0>{}, requests);
+                mma_step(std::integral_constant<int, K1>{}, []() {});
+            } else {
+                requests();
+            }
+            if constexpr (HAS_PREV && PP >= 1) {
+                if (!(G3_DBG & 4)) {
+                    epi_sub(std::integral_constant<int, K0 - 2>{});
+                    epi_sub(std::integral_constant<int, K1 - 2>{});
+                }
+            }
+            if (G3_TRACE && HAS_CUR) { __builtin_amdgcn_sched_barrier(0); trace(PP, 2); }
+        };
+        kpair(std::integral_constant<int, 0>{});
+        kpair(std::integral_constant<int, 1>{});
+        kpair(std::integral_constant<int, 2>{});
+    };
+
+    // ---- the unit stream, two accumulator sets alternating
+    v16i acc0[2][2], acc1[2][2];
+    int u_cur = u_first;
+    auto locate = [&](int u, G3Tile &t) __attribute__((always_inline)) {
+        const int tm = u / p.tiles_n;
+        t.row0 = tm << 8;
+        t.col0 = (u - tm * p.tiles_n) << 7;
+    };
+    G3Tile cur{0, 0, 0}, prev{0, 0, 0}, nxt{0, 0, 0};
+    locate(u_cur, cur);
+    locate(u_cur + 1, nxt);
+    auto advance = [&]() __attribute__((always_inline)) {
+        prev = cur;
+        ++u_cur;
+        const int par = cur.par == 2 ? 0 : cur.par + 1;
+        cur = nxt;
+        cur.par = par;
+        locate(u_cur + 1, nxt);
+        return u_cur < u_end;
+    };
+    const std::true_type T{};
+    const std::false_type F{};
+    tile_body(T, F, acc0, acc1, cur, prev, u_cur + 1 < u_end, nxt.col0);
+    for (;;) {
+        if (!advance()) { tile_body(F, T, acc1, acc0, cur, prev, false, 0); break; }
+        tile_body(T, T, acc1, acc0, cur, prev, u_cur + 1 < u_end, nxt.col0);
+        if (!advance()) { tile_body(F, T, acc0, acc1, cur, prev, false, 0); break; }
+        tile_body(T, T, acc0, acc1, cur, prev, u_cur + 1 < u_end, nxt.col0);
+    }
+    if (G3_TRACE && bid == 0) {
+        __syncthreads();
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(p.dummy) + 1024);
+        const unsigned long long *tb = reinterpret_cast<const unsigned long long *>(smem + GA_SMEM);
+        for (int k = tid; k < GA_TRACE_BYTES / 8; k += 512) dst[k] = tb[k];
+    }
+}

@@ -4,11 +4,13 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <new>
 #include "ivit_device.h"
 #include "ivit_elementwise.h"
 #include "ivit_gemm.h"
 #include "ivit_attention.h"
 #include "ivit_gemm2.h"
+#include "ivit_gemm3.h"
 #include "ivit_swin.h"
 
 struct ivit_ctx {
@@ -251,6 +253,184 @@ int ivit_attn_pv_requant(ivit_handle h, const uint16_t *p, const int8_t *vt, ivi
     a.strideA = (long long)T * ldp; a.strideB = (long long)dh * ldv;
     a.inner = H; a.sC_outer = (long long)T * H * dh; a.sC_inner = dh; a.out = ctx8; a.dy_main = dy;
     return launch_gemm<true, EPI_RQ8_S>(h, a, B * H);
+}
+
+}  // extern "C"
+
+
+// ---------------------------------------------------------------- linear plans (frozen QuantLinear)
+// One wavefront per output channel: c[n] = m*2^-e, zmax[n] = 128 * sum_k |W[n,k]| + |bias[n]| >= |acc + bias|.
+// bad bit 0: |zmax * c| >= 2^31 (the magic-number rounding of the pipelined epilogue could wrap);
+// bad bit 1: zmax * |m| >= 2^53 (z*m inexact in fp64: the single-FMA form is not the reference's two roundings).
+__global__ __launch_bounds__(256) void linear_plan_kernel(const int8_t *__restrict__ w, const int32_t *__restrict__ bias,
+                                                          const ivit_dyadic *__restrict__ dy, int N, int K,
+                                                          double *__restrict__ cq, int *__restrict__ bad) {
+    const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const int8_t *wp = w + (long long)n * K;
+    int l1 = 0;
+    for (int k = lane; k < K; k += 64) l1 += abs((int)wp[k]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) l1 += __shfl_xor(l1, o);
+    if (lane == 0) {
+        const double c = dy[n].m * dy[n].r;
+        cq[n] = c;
+        const double zmax = 128.0 * (double)l1 + fabs((double)(bias ? bias[n] : 0));
+        int b = 0;
+        if (!(fabs(c) * zmax < 2147483000.0)) b |= 1;
+        if (!(fabs(dy[n].m) * zmax < 9007199254740992.0)) b |= 2;
+        if (b) atomicOr(bad, b);
+    }
+}
+
+struct ivit_linear_plan_s {
+    const int8_t *w;
+    const int32_t *bias;        // caller's pointer (may be null)
+    const int32_t *bias_eff;    // never null: zeros inside `dev` when the layer has no bias
+    const ivit_dyadic *dy;
+    int N, K;
+    char *dev;                  // one allocation: cq[N] doubles | zero bias (optional) | flag word | 1 KB store scratch
+    double *cq;
+    void *dummy;
+    int pipelined_ok, single_fma_ok;
+};
+
+extern "C" {
+
+int ivit_linear_plan_create(ivit_handle h, const int8_t *w, const int32_t *bias, const ivit_dyadic *dy_ch, int N, int K,
+                            ivit_linear_plan *out) {
+    CHECK_H(h);
+    REQUIRE(h, w && dy_ch && out && N > 0 && K > 0, "bad arguments");
+    if (hipSetDevice(h->device) != hipSuccess) return IVIT_ERR_HIP;
+    const size_t cq_bytes = ((size_t)N * 8 + 255) & ~(size_t)255, b_bytes = ((size_t)N * 4 + 255) & ~(size_t)255;
+    char *dev = nullptr;
+    hipError_t e = hipMalloc((void **)&dev, cq_bytes + b_bytes + 256 + 1024 + 8192);
+    if (e != hipSuccess) { snprintf(h->err, sizeof(h->err), "ivit_linear_plan_create: hipMalloc: %s", hipGetErrorString(e)); return IVIT_ERR_HIP; }
+    int *flag = (int *)(dev + cq_bytes + b_bytes);
+    int host_bad = 3;
+    bool ok = hipMemsetAsync(dev + cq_bytes, 0, b_bytes + 256 + 1024 + 8192, h->stream) == hipSuccess;
+    if (ok) {
+        linear_plan_kernel<<<(N + 3) / 4, 256, 0, h->stream>>>(w, bias, dy_ch, N, K, (double *)dev, flag);
+        ok = hipGetLastError() == hipSuccess;
+    }
+    ok = ok && hipMemcpyAsync(&host_bad, flag, sizeof(int), hipMemcpyDeviceToHost, h->stream) == hipSuccess;
+    ok = ok && hipStreamSynchronize(h->stream) == hipSuccess;      // plan creation is a build-time call
+    if (!ok) {
+        snprintf(h->err, sizeof(h->err), "ivit_linear_plan_create: HIP error");
+        (void)hipFree(dev);
+        return IVIT_ERR_HIP;
+    }
+    ivit_linear_plan_s *p = new (std::nothrow) ivit_linear_plan_s();
+    if (!p) { (void)hipFree(dev); return IVIT_ERR_HIP; }
+    p->w = w; p->bias = bias; p->dy = dy_ch; p->N = N; p->K = K; p->dev = dev; p->cq = (double *)dev;
+    p->bias_eff = bias ? bias : (const int32_t *)(dev + cq_bytes);
+    p->dummy = dev + cq_bytes + b_bytes + 256;
+    p->pipelined_ok = !(host_bad & 1);
+    p->single_fma_ok = !(host_bad & 2);
+    *out = p;
+    return IVIT_OK;
+}
+
+int ivit_linear_plan_destroy(ivit_linear_plan p) {
+    if (!p) return IVIT_ERR_INVALID;
+    (void)hipFree(p->dev);
+    delete p;
+    return IVIT_OK;
+}
+
+int ivit_debug_plan_scratch(ivit_linear_plan p, void *host_dst, int nbytes) {
+    if (!p || !host_dst || nbytes <= 0 || nbytes > 8192) return IVIT_ERR_INVALID;
+    if (hipDeviceSynchronize() != hipSuccess) return IVIT_ERR_HIP;
+    return hipMemcpy(host_dst, (char *)p->dummy + 1024, (size_t)nbytes, hipMemcpyDeviceToHost) == hipSuccess ? IVIT_OK : IVIT_ERR_HIP;
+}
+
+int ivit_linear_plan_query(ivit_linear_plan p, int *pipelined_ok, int *single_fma_ok) {
+    if (!p) return IVIT_ERR_INVALID;
+    if (pipelined_ok) *pipelined_ok = p->pipelined_ok;
+    if (single_fma_ok) *single_fma_ok = p->single_fma_ok;
+    return IVIT_OK;
+}
+
+}  // extern "C"
+
+// persistent pipelined kernel: shapes it is built for (anything else runs on gemm_glds_kernel / gemm_nt_kernel)
+static inline bool use_gemm3(const ivit_linear_plan_s *pl, const GemmArgs &a) {
+    static const int on = env_int("IVIT_GEMM3", 1);
+    return on && pl->pipelined_ok && (a.K % 64) == 0 && a.K >= 320 && (a.N % 16) == 0 && (a.ldc % 16) == 0 &&
+           (a.lda % 16) == 0 && (a.ldb % 16) == 0 && a.M >= 128;
+}
+
+template <int EPI>
+static int launch_gemm3(ivit_handle h, const ivit_linear_plan_s *pl, GemmArgs &a) {
+    a.tiles_n = (a.N + 127) / 128;
+    a.cq = pl->cq;
+    a.bias = pl->bias_eff;
+    a.dummy = pl->dummy;
+    static const int force_fma = env_int("IVIT_GEMM3_FMA", -1), wg_per_cu = env_int("IVIT_GEMM3_WGS", 2);
+    static const int dbg3 = env_int("IVIT_GEMM3_DBG", 0), astat_on = env_int("IVIT_GEMM3_ASTAT", 1);
+    a.dbg = dbg3;
+    const bool fma = force_fma >= 0 ? (force_fma != 0 && pl->single_fma_ok) : (pl->single_fma_ok != 0);
+    // A-stationary kernel: K == 384; the qkv scatter additionally needs whole units inside one of q / k / v and
+    // whole 32-channel groups inside one head
+    const bool astat = astat_on && a.K == 64 * GA_NK && a.M >= 256 && (a.N % 32) == 0 &&
+                       (EPI != EPI_QKV || ((a.D % 128) == 0 && (a.dh % 32) == 0));
+    if (astat) {
+        const long long nunits = (long long)((a.M + 255) / 256) * a.tiles_n;
+        long long grid = h->num_cu;
+        if (grid > nunits) grid = nunits;
+        if (fma) gemm_as_kernel<EPI, true><<<dim3((unsigned)grid), 512, 0, h->stream>>>(a);
+        else gemm_as_kernel<EPI, false><<<dim3((unsigned)grid), 512, 0, h->stream>>>(a);
+    } else {
+        const long long nunits = (long long)((a.M + 127) / 128) * a.tiles_n;
+        long long grid = (long long)h->num_cu * wg_per_cu;
+        if (grid > nunits) grid = nunits;
+        if (fma) gemm_ps_kernel<EPI, true, false><<<dim3((unsigned)grid), 256, 0, h->stream>>>(a);
+        else gemm_ps_kernel<EPI, false, false><<<dim3((unsigned)grid), 256, 0, h->stream>>>(a);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(h->err, sizeof(h->err), "gemm3 launch: %s", hipGetErrorString(e));
+        return IVIT_ERR_HIP;
+    }
+    return IVIT_OK;
+}
+
+extern "C" {
+
+int ivit_linear_i8_requant_planned(ivit_handle h, ivit_linear_plan pl, const int8_t *x, int bits, void *out, int M) {
+    CHECK_H(h);
+    REQUIRE(h, pl && x && out && M > 0, "bad arguments");
+    REQUIRE(h, bits == 8 || bits == 16, "bits must be 8 or 16");
+    GemmArgs a = linear_args(x, pl->w, pl->bias, M, pl->N, pl->K);
+    a.out = out; a.dy_ch = pl->dy;
+    if (use_gemm3(pl, a)) return bits == 8 ? launch_gemm3<EPI_RQ8_CH>(h, pl, a) : launch_gemm3<EPI_RQ16_CH>(h, pl, a);
+    return ivit_linear_i8_requant(h, x, pl->w, pl->bias, pl->dy, bits, out, M, pl->N, pl->K);
+}
+
+int ivit_linear_i8_requant_residual_planned(ivit_handle h, ivit_linear_plan pl, const int8_t *x, ivit_dyadic dy_main,
+                                            ivit_dyadic dy_res, const int16_t *residual, int16_t *out, int M) {
+    CHECK_H(h);
+    REQUIRE(h, pl && x && out && residual && M > 0, "bad arguments");
+    GemmArgs a = linear_args(x, pl->w, pl->bias, M, pl->N, pl->K);
+    a.out = out; a.dy_ch = pl->dy; a.dy_main = dy_main; a.dy_res = dy_res; a.residual = residual;
+    const bool res_fast = fabs(dy_main.m * dy_main.r) < RQ_FAST_CLIM && fabs(dy_res.m * dy_res.r) < RQ_FAST_CLIM;
+    if (use_gemm3(pl, a) && res_fast) return launch_gemm3<EPI_RQ16_CH_RES>(h, pl, a);
+    return ivit_linear_i8_requant_residual(h, x, pl->w, pl->bias, pl->dy, dy_main, dy_res, residual, out, M, pl->N, pl->K);
+}
+
+int ivit_linear_i8_qkv_planned(ivit_handle h, ivit_linear_plan pl, const int8_t *x, int8_t *q, int8_t *k, int8_t *vt,
+                               int B, int T, int H, int dh, int ldv) {
+    CHECK_H(h);
+    REQUIRE(h, pl && x && q && k && vt && B > 0 && T > 0 && H > 0 && dh > 0, "bad arguments");
+    REQUIRE(h, (dh % 16) == 0, "head dim must be a multiple of 16");
+    REQUIRE(h, ldv >= T, "ldv < T");
+    const int D = H * dh;
+    REQUIRE(h, pl->N == 3 * D && pl->K == D, "plan shape is not [3*H*dh, H*dh]");
+    GemmArgs a = linear_args(x, pl->w, pl->bias, B * T, 3 * D, D);
+    a.dy_ch = pl->dy; a.q = q; a.k = k; a.vt = vt;
+    a.T = T; a.H = H; a.dh = dh; a.ldv = ldv; a.D = D;
+    if (use_gemm3(pl, a) && (long long)B * T < (1 << 23)) return launch_gemm3<EPI_QKV>(h, pl, a);
+    return ivit_linear_i8_qkv(h, x, pl->w, pl->bias, pl->dy, q, k, vt, B, T, H, dh, ldv);
 }
 
 }  // extern "C"

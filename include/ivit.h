@@ -92,6 +92,28 @@ int ivit_linear_i8_qkv(ivit_handle h, const int8_t *x, const int8_t *w, const in
                        const ivit_dyadic *dy_ch, int8_t *q, int8_t *k, int8_t *vt, int B, int T,
                        int H, int dh, int ldv);
 
+/* ---- linear plans: a frozen QuantLinear prepared once (quant_modules.py:67-97 with QuantAct.fix(), :153-157).
+ * ivit_linear_plan_create precomputes the per-channel multipliers c[n] = m*2^-e and checks, from
+ * sum_k |w[n,k]| and bias[n], the two bounds under which the persistent pipelined GEMM (csrc/ivit_gemm3.h)
+ * is bit-identical to the reference arithmetic.  It allocates a small device buffer and SYNCHRONISES the
+ * handle's stream: a build-time call (freeze), never on the per-batch path.  w / bias / dy_ch must outlive
+ * the plan.  The *_planned entry points are drop-ins for the unplanned ones above (same results bit for bit);
+ * shapes or constants outside the pipelined kernel's contract run on the launch-per-tile kernels.          */
+typedef struct ivit_linear_plan_s *ivit_linear_plan;
+int ivit_linear_plan_create(ivit_handle h, const int8_t *w, const int32_t *bias, const ivit_dyadic *dy_ch, int N, int K,
+                            ivit_linear_plan *out);
+int ivit_linear_plan_destroy(ivit_linear_plan p);
+/* pipelined_ok: the persistent kernel may be used; single_fma_ok: its one-FMA requant form is exact.        */
+int ivit_linear_plan_query(ivit_linear_plan p, int *pipelined_ok, int *single_fma_ok);
+/* debug: copy the 8 KB behind the plan's store scratch to the host (kernel timeline traces of -DG3_TRACE builds;
+ * zeros in production builds).  Synchronises the device.                                                     */
+int ivit_debug_plan_scratch(ivit_linear_plan p, void *host_dst, int nbytes);
+int ivit_linear_i8_requant_planned(ivit_handle h, ivit_linear_plan p, const int8_t *x, int bits, void *out, int M);
+int ivit_linear_i8_requant_residual_planned(ivit_handle h, ivit_linear_plan p, const int8_t *x, ivit_dyadic dy_main,
+                                            ivit_dyadic dy_res, const int16_t *residual, int16_t *out, int M);
+int ivit_linear_i8_qkv_planned(ivit_handle h, ivit_linear_plan p, const int8_t *x, int8_t *q, int8_t *k, int8_t *vt,
+                               int B, int T, int H, int dh, int ldv);
+
 /* ---- a2  QuantMatMul.forward  (quant_modules.py:223-228), batched, "NT" form:
  * C[b] = A[b] (M x K) * B[b]^T (B[b] is N x K), int32.  q·kᵀ: A=q, B=k.
  * lda/ldb/ldc in elements, strides per batch in elements; lda,ldb % 16 == 0.            */

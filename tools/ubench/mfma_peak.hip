@@ -58,8 +58,9 @@ void run(int *buf, int blocks_per_cu, int seed) {
     hipEventSynchronize(b);
     float ms;
     hipEventElapsedTime(&ms, a, b);
-    // per wave per iteration: 8 MFMAs of 2*32*32*32 = 65536 OP (both shapes)
-    double ops = (double)grid.x * 4 * n * 8 * 65536.0;
+    // per wave per iteration: 8 MFMAs; 32x32x32 = 2*32*32*32 = 65536 OP, 16x16x64 = 2*16*16*64 = 32768 OP
+    const double op_per_mfma = SHAPE == 32 ? 65536.0 : 32768.0;
+    double ops = (double)grid.x * 4 * n * 8 * op_per_mfma;
     printf("mfma %s  %d waves/SIMD  %-6s operands: %8.3f ms  %7.1f TOP/s  (%.1f cyc/MFMA/SIMD at 2.4 GHz)\n",
            SHAPE == 32 ? "32x32x32" : "16x16x64", blocks_per_cu, seed ? "random" : "zero", ms, ops / ms / 1e9,
            ms * 1e-3 * 2.4e9 / ((double)blocks_per_cu * n * 8));
