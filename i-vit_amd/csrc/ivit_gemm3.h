@@ -532,6 +532,12 @@ __device__ __forceinline__ void ga_wait_vm(int n) {
         :: "s"(off) : "vcc", "scc", "memory");
 }
 
+// 16-byte LDS read at an explicit LDS byte address (one base register + immediate offset)
+__device__ __forceinline__ v4i ga_lds_read16(unsigned lds_addr) {
+    typedef __attribute__((address_space(3))) const v4i lds_v4i_t;
+    return *(lds_v4i_t *)(lds_addr);
+}
+
 // swap the upper-half lanes of `a` with the lower-half lanes of `b`
 __device__ __forceinline__ void ga_swap32(int &a, int &b) {
     typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
@@ -540,15 +546,29 @@ __device__ __forceinline__ void ga_swap32(int &a, int &b) {
     b = (int)r[1];
 }
 
+struct GaUnit {
+    int row0, col0;   // first token / channel
+    int cb;           // constants buffer (0..2)
+    int need_a;       // first unit of its panel inside this workgroup: brings the panel's A slices along
+    int valid;
+};
+
+// one 1 KB piece of an operand slice by DMA: uniform 64-bit base + per-lane 32-bit offset (the saddr + voffset form:
+// no per-lane 64-bit address arithmetic), LDS destination = uniform base (M0) + lane * 16
+__device__ __forceinline__ void ga_dma16(const int8_t *base, unsigned voff, int imm, unsigned lds_uniform) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + (size_t)voff + imm),
+                                     (__attribute__((address_space(3))) void *)(size_t)lds_uniform, 16, 0, 0);
+}
+
 template <int EPI, bool FMA>
 __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[GA_SMEM + GA_TRACE_BYTES];
-    char *const ring = smem + GA_PANEL;
-    char *const cst0 = ring + GA_RING;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1, half = lane >> 5;
     constexpr bool OUT8 = (EPI == EPI_RQ8_CH || EPI == EPI_QKV);
     constexpr bool RES = (EPI == EPI_RQ16_CH_RES);
+    const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+    const unsigned ring_lds = smem_lds + GA_PANEL, cst_lds = ring_lds + GA_RING;
 
     // ---- this workgroup's contiguous unit range; unit u = (256-token panel u / tiles_n, 128-channel tile u % tiles_n).
     // Ranges are handed out so that the workgroups of one XCD (b % 8) hold neighbouring ranges.
@@ -566,36 +586,53 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
     // mark[k] = count right after the slices of k-step k (ring slot k) were requested
     int issued = 0, mark[GA_NK] = {0, 0, 0, 0, 0, 0}, mark_res[4] = {0, 0, 0, 0}, mark_cst = 0;
 
-    // ---- load cursor: two pairs of k-steps ahead of the MFMAs, across unit boundaries
-    int u_load = u_first, l_kt = 0;
-    int l_tm = u_load / p.tiles_n, l_tn = u_load - l_tm * p.tiles_n;
-    int l_need_a = 1;             // this unit brings its panel's slices along (int: a by-reference bool lands in scratch)
-    auto issue_next = [&](auto slot_t) __attribute__((always_inline)) {
-        constexpr int SLOT = decltype(slot_t)::value;           // == l_kt (the stream advances one k-step per call)
-        if (u_load >= u_end) return;
-        const bool skip = (G3_DBG & 1) && u_load != u_first;     // ablation: no operand traffic after the first unit
-        if (l_need_a) {
-            if (!skip) { g3_issue_a256(A, p.lda, p.M, l_tm << 8, SLOT * G2_BK, smem + SLOT * 16384, tid); issued += 2; }
-        }
-        if (!skip) { g3_issue_w128(B, p.ldb, p.N, l_tn << 7, SLOT * G2_BK, ring + SLOT * GA_WSTAGE, tid); issued += 1; }
-        mark[SLOT] = issued;
-        if (++l_kt == GA_NK) {
-            l_kt = 0;
-            ++u_load;
-            l_need_a = 0;
-            if (++l_tn == p.tiles_n) { l_tn = 0; ++l_tm; l_need_a = 1; }
-        }
+    // ---- operand DMA.  Piece -> (row, 16-byte chunk) as in g2_issue: the LDS image [row][64] is XOR-swizzled through
+    // the SOURCE chunk.  Per-lane byte offsets (relative to A / B) are recomputed once per panel / per unit; a slice
+    // then costs one scalar add for M0 and the instruction itself.
+    const int a_row0 = tid >> 2, a_row1 = (tid + 512) >> 2, w_row = tid >> 2;
+    const int a_c0 = ((tid & 3) ^ ((a_row0 >> 2) & 3)) * 16, a_c1 = ((tid & 3) ^ ((a_row1 >> 2) & 3)) * 16;
+    unsigned a_off0 = 0, a_off1 = 0, w_off = 0;
+    auto set_panel = [&](int row0) __attribute__((always_inline)) {
+        a_off0 = (unsigned)min(row0 + a_row0, p.M - 1) * (unsigned)p.lda + a_c0;
+        a_off1 = (unsigned)min(row0 + a_row1, p.M - 1) * (unsigned)p.lda + a_c1;
     };
-    auto issue_consts = [&](int col0, int par) __attribute__((always_inline)) {
-        g3_issue_consts(p, col0, cst0 + par * G3_CONST_BYTES, wave, lane);
+    auto set_wtile = [&](int col0) __attribute__((always_inline)) {
+        w_off = (unsigned)min(col0 + w_row, p.N - 1) * (unsigned)p.ldb + a_c0;      // same chunk swizzle: row = tid >> 2
+    };
+    const unsigned dma_lane0 = wave * 1024;
+    auto issue_slice = [&](auto s_t, const GaUnit &u) __attribute__((always_inline)) {
+        constexpr int S = decltype(s_t)::value;
+        if (!((G3_DBG & 1) && u.row0 + u.col0 != 0)) {
+            if (u.need_a) {
+                ga_dma16(A, a_off0, S * 64, smem_lds + S * 16384 + dma_lane0);
+                ga_dma16(A, a_off1, S * 64, smem_lds + S * 16384 + 8192 + dma_lane0);
+                issued += 2;
+            }
+            ga_dma16(B, w_off, S * 64, ring_lds + S * GA_WSTAGE + dma_lane0);
+            issued += 1;
+        }
+        mark[S] = issued;
+    };
+    auto issue_consts = [&](int col0, int cb) __attribute__((always_inline)) {
+        g3_issue_consts(p, col0, smem + GA_PANEL + GA_RING + cb * G3_CONST_BYTES, wave, lane);
         if (wave < 3) issued += 1;
         mark_cst = issued;
     };
-    issue_consts(l_tn << 7, 0);
-    issue_next(std::integral_constant<int, 0>{});
-    issue_next(std::integral_constant<int, 1>{});
-    issue_next(std::integral_constant<int, 2>{});
-    issue_next(std::integral_constant<int, 3>{});
+
+    // ---- MFMA fragment / constant addresses.  The LDS image is 148 KB but a DS instruction's immediate offset
+    // stops at 64 KB: left alone, the compiler keeps one address register per (k-step, operand).  Opaque per-lane
+    // bases reach every fragment with an immediate.
+    unsigned fa_lo[2], fa_hi[2], fw[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        fa_lo[kk] = smem_lds + lds_off(wm * 64 + (lane & 31), kk * 2 + half);
+        fa_hi[kk] = fa_lo[kk] + 4 * 16384;
+        fw[kk] = ring_lds + lds_off(wn * 64 + (lane & 31), kk * 2 + half);
+        asm volatile("" : "+v"(fa_lo[kk]), "+v"(fa_hi[kk]), "+v"(fw[kk]));
+    }
+    unsigned pc_lds = cst_lds + (wn * 64 + half * 4) * 8;          // this lane's first multiplier, buffer 0
+    unsigned pb_lds = cst_lds + 1024 + (wn * 64 + half * 4) * 4;   // this lane's first bias word, buffer 0
+    asm volatile("" : "+v"(pc_lds), "+v"(pb_lds));
 
     const double cm = p.dy_main.m * p.dy_main.r, cr = p.dy_res.m * p.dy_res.r;
     const float rcpT = 1.0f / (float)(p.T > 0 ? p.T : 1);
@@ -606,18 +643,18 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
             tb[(wave * 3 + tr_unit) * 24 + kt * 4 + pt] = __builtin_readcyclecounter();
         }
     };
-    v4i resv[8];          // residual pieces in flight / waiting for their sub-tile's epilogue (two k-steps later): [(j*2 + i)*2 + piece]
+    v4i resv[8];          // residual pieces in flight / waiting for their sub-tile's epilogue: [(j*2 + i)*2 + piece]
     (void)resv;
 
     // token row / channel column of this lane's 16-channel run in sub-tile (i, j) of a unit
-    auto sub_row = [&](const G3Tile &t, int i) __attribute__((always_inline)) { return t.row0 + wm * 64 + i * 32 + (lane & 31); };
-    auto sub_col = [&](const G3Tile &t, int j) __attribute__((always_inline)) { return t.col0 + wn * 64 + j * 32 + half * 16; };
+    auto sub_row = [&](const GaUnit &t, int i) __attribute__((always_inline)) { return t.row0 + wm * 64 + i * 32 + (lane & 31); };
+    auto sub_col = [&](const GaUnit &t, int j) __attribute__((always_inline)) { return t.col0 + wn * 64 + j * 32 + half * 16; };
 
-    auto tile_body = [&](auto has_cur_t, auto has_prev_t, v16i(&accC)[2][2], v16i(&accP)[2][2], const G3Tile cur,
-                         const G3Tile prev, const bool has_next, const int next_col0) __attribute__((always_inline)) {
+    // ------------------------------------------------------------------------------------------------
+    // one unit: K loop of `cur` into accC (HAS_CUR) with the epilogue of `prev` out of accP (HAS_PREV)
+    auto tile_body = [&](auto has_cur_t, auto has_prev_t, v16i(&accC)[2][2], v16i(&accP)[2][2], const GaUnit cur,
+                         const GaUnit prev, const GaUnit next) __attribute__((always_inline)) {
         constexpr bool HAS_CUR = decltype(has_cur_t)::value, HAS_PREV = decltype(has_prev_t)::value;
-        const double *pc = reinterpret_cast<const double *>(cst0 + prev.par * G3_CONST_BYTES);
-        const char *ccst = cst0 + cur.par * G3_CONST_BYTES;
 
         // ---- epilogue of sub-tile (i, j) of `prev`: requant -> pack -> half-wave exchange -> store
         auto epi_sub = [&](auto c_t) __attribute__((always_inline)) {
@@ -625,21 +662,29 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
             const v16i &acc = accP[i][j];
             const int grow = sub_row(prev, i), gcol = sub_col(prev, j);
             const bool ok = grow < p.M && gcol < p.N;
-            const int nl0 = wn * 64 + j * 32 + half * 4;
-            auto rq = [&](int g, int e) __attribute__((always_inline)) {
-                const int z = acc[g * 4 + e];
-                const double c = pc[nl0 + g * 8 + e];
-                const double t = FMA ? __builtin_fma((double)z, c, G3_MAGIC) : ((double)z * c + G3_MAGIC);
-                const int v = __double2loint(t);
-                return OUT8 ? min(max(v, -128), 127) : min(max(v, -32768), 32767);
+            typedef double v2d __attribute__((ext_vector_type(2)));
+            const unsigned cads = pc_lds + (unsigned)prev.cb * G3_CONST_BYTES + j * 256;
+            // requant of quad g: 4 consecutive channels 8g + 4*half + e
+            auto rq4 = [&](int g, int(&o)[4]) __attribute__((always_inline)) {
+                const v2d c01 = __builtin_bit_cast(v2d, ga_lds_read16(cads + g * 64));
+                const v2d c23 = __builtin_bit_cast(v2d, ga_lds_read16(cads + g * 64 + 16));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int z = acc[g * 4 + e];
+                    const double c = e < 2 ? c01[e] : c23[e - 2];
+                    const double t = FMA ? __builtin_fma((double)z, c, G3_MAGIC) : ((double)z * c + G3_MAGIC);
+                    const int v = __double2loint(t);
+                    o[e] = OUT8 ? min(max(v, -128), 127) : min(max(v, -32768), 32767);
+                }
             };
             if constexpr (OUT8) {
                 int d[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int o0 = rq(g, 0), o1 = rq(g, 1), o2 = rq(g, 2), o3 = rq(g, 3);
-                    const unsigned w01 = __builtin_amdgcn_perm((unsigned)o1, (unsigned)o0, 0x0c0c0400u);
-                    const unsigned w23 = __builtin_amdgcn_perm((unsigned)o3, (unsigned)o2, 0x0c0c0400u);
+                    int o[4];
+                    rq4(g, o);
+                    const unsigned w01 = __builtin_amdgcn_perm((unsigned)o[1], (unsigned)o[0], 0x0c0c0400u);
+                    const unsigned w23 = __builtin_amdgcn_perm((unsigned)o[3], (unsigned)o[2], 0x0c0c0400u);
                     d[g] = (int)__builtin_amdgcn_perm(w23, w01, 0x05040100u);
                 }
                 // lower half-wave: channels 0..15 of the token = {h0.d0, h1.d0, h0.d1, h1.d1}; upper: 16..31
@@ -684,9 +729,10 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
                     int w[2][2];
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
-                        const int g = h2 + 2 * q;
-                        w[q][0] = (int)__builtin_amdgcn_perm((unsigned)rq(g, 1), (unsigned)rq(g, 0), 0x05040100u);
-                        w[q][1] = (int)__builtin_amdgcn_perm((unsigned)rq(g, 3), (unsigned)rq(g, 2), 0x05040100u);
+                        int o[4];
+                        rq4(h2 + 2 * q, o);
+                        w[q][0] = (int)__builtin_amdgcn_perm((unsigned)o[1], (unsigned)o[0], 0x05040100u);
+                        w[q][1] = (int)__builtin_amdgcn_perm((unsigned)o[3], (unsigned)o[2], 0x05040100u);
                     }
                     ga_swap32(w[0][0], w[1][0]);
                     ga_swap32(w[0][1], w[1][1]);
@@ -712,9 +758,10 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
             }
         };
 
-        // residual of sub-tile C of unit `t`, in the epilogue's register layout; requested two k-steps before its
-        // epilogue step (8 registers per sub-tile in flight instead of 32 for the whole unit)
-        auto res_request = [&](auto c_t, const G3Tile &t) __attribute__((always_inline)) {
+        // residual of sub-tile C of unit `t`, in the epilogue's register layout; requested a pair before its epilogue,
+        // inside the same straight-line body (a value an asm load is still filling must not cross a loop edge: the
+        // register allocator may copy it)
+        auto res_request = [&](auto c_t, const GaUnit &t) __attribute__((always_inline)) {
             constexpr int C = decltype(c_t)::value;
             const int grow = sub_row(t, C & 1), gcol = sub_col(t, C >> 1);
             const bool ok = grow < p.M && gcol < p.N;
@@ -725,56 +772,33 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
             mark_res[C] = issued;
         };
 
-        // MFMAs of k-step KT; `between` runs after the first half's MFMAs are issued (the DMA requests go there:
-        // a global_load_lds costs the issuing wave ~100+ cycles, which the matrix pipe spends on those MFMAs)
-        auto mma_step = [&](auto kt_t, auto between) __attribute__((always_inline)) {
-            constexpr int KT = decltype(kt_t)::value;
-            const char *sA = smem + KT * 16384;
-            const char *sB = ring + KT * GA_WSTAGE;
+        // 4 MFMAs: columns [32 kk, 32 kk + 32) of k-step KT
+        auto mma_group = [&](auto kt_t, auto kk_t) __attribute__((always_inline)) {
+            constexpr int KT = decltype(kt_t)::value, kk = decltype(kk_t)::value;
+            const unsigned sA = (KT < 4 ? fa_lo[kk] + KT * 16384 : fa_hi[kk] + (KT - 4) * 16384);
+            const unsigned sB = fw[kk] + KT * GA_WSTAGE;
             v4i a[2], b[2];
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const int chunk = kk * 2 + half;
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    a[i] = *reinterpret_cast<const v4i *>(sA + lds_off(wm * 64 + i * 32 + (lane & 31), chunk));
-                    b[i] = *reinterpret_cast<const v4i *>(sB + lds_off(wn * 64 + i * 32 + (lane & 31), chunk));
-                }
-                if (KT == 0 && kk == 0) {
-                    // first MFMA of the unit: C operand = bias (lane: channels 32j + 8g + 4*half + e)
-                    const int *bp = reinterpret_cast<const int *>(ccst + 1024) + wn * 64 + half * 4;
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        v16i init;
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const v4i bv = *reinterpret_cast<const v4i *>(bp + j * 32 + g * 8);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) init[g * 4 + e] = bv[e];
-                        }
-#pragma unroll
-                        for (int i = 0; i < 2; ++i)
-                            accC[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b[j], a[i], init, 0, 0, 0);
-                    }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            accC[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b[j], a[i], accC[i][j], 0, 0, 0);
-                }
-                if (kk == 0) between();
+            for (int i = 0; i < 2; ++i) {
+                a[i] = ga_lds_read16(sA + i * 2048);
+                b[i] = ga_lds_read16(sB + i * 2048);
             }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    accC[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b[j], a[i], accC[i][j], 0, 0, 0);
         };
 
         // ---- one PAIR of k-steps (K0 = 2P, K1 = 2P + 1) behind one barrier.  The barrier publishes the slices of
-        // both steps (requested 4..5 steps ago) and frees the ring slots of the previous pair, which this pair's
-        // DMA requests refill for the pair after next.  Everything after the barrier is ONE basic block.
+        // both steps (requested two pairs ago) and frees the ring slots of the previous pair, which this pair's DMA
+        // requests refill for the pair after next: slices 4, 5 of this unit (pair 0) or 0..3 of the next (pairs 1, 2).
+        // Everything after the barrier is ONE basic block apart from the uniform tests around the DMA requests.
         auto kpair = [&](auto p_t) __attribute__((always_inline)) {
             constexpr int PP = decltype(p_t)::value, K0 = 2 * PP, K1 = K0 + 1;
-            // slices of K1 (requested after K0's) landed; the residual pieces of the sub-tiles whose epilogue runs in
-            // this pair (requested a pair ago); at pair 0 the unit's constants (requested at pair 2 of the previous unit)
             {
+                // slices of K1 (requested after K0's) landed; the residual pieces of the sub-tiles finished in this pair;
+                // at pair 0 the unit's constants (requested at pair 2 of the previous unit, AFTER this pair's slices)
                 int n = 1 << 20;
                 if (HAS_CUR) n = issued - mark[K1];
                 if (HAS_CUR && PP == 0) n = min(n, issued - mark_cst);
@@ -791,25 +815,38 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
             asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             if (G3_TRACE && HAS_CUR) { if (PP == 0) ++tr_unit; trace(PP, 0); }
-            auto requests = [&]() __attribute__((always_inline)) {
-                if (HAS_CUR) {
-                    issue_next(std::integral_constant<int, (K0 + 4) % GA_NK>{});
-                    issue_next(std::integral_constant<int, (K1 + 4) % GA_NK>{});
-                    if (PP == 2 && has_next) issue_consts(next_col0, cur.par == 2 ? 0 : cur.par + 1);
+            if (HAS_CUR && PP == 0) {
+                // the accumulators start at the bias (lane: channels 32j + 8g + 4*half + e)
+                const unsigned bads = pb_lds + (unsigned)cur.cb * G3_CONST_BYTES;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const v4i bv = ga_lds_read16(bads + j * 128 + g * 32);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { accC[0][j][g * 4 + e] = bv[e]; accC[1][j][g * 4 + e] = bv[e]; }
+                    }
+            }
+            if (HAS_CUR && !(G3_DBG & 2)) mma_group(std::integral_constant<int, K0>{}, std::integral_constant<int, 0>{});
+            // DMA requests after the first MFMAs are in the pipe
+            if (HAS_CUR) {
+                const GaUnit &lu = PP == 0 ? cur : next;
+                if (lu.valid) {
+                    if (PP == 1) { set_wtile(lu.col0); if (lu.need_a) set_panel(lu.row0); }
+                    issue_slice(std::integral_constant<int, (K0 + 4) % GA_NK>{}, lu);
+                    issue_slice(std::integral_constant<int, (K1 + 4) % GA_NK>{}, lu);
+                    if (PP == 2) issue_consts(lu.col0, lu.cb);
                 }
-                // residual of the sub-tiles finished in the NEXT pair: requested inside the same straight-line body
-                // (a value an asm load is still filling must not cross a loop edge: the register allocator may copy it)
-                if constexpr (RES && HAS_PREV && PP < 2) {
-                    res_request(std::integral_constant<int, K0>{}, prev);
-                    res_request(std::integral_constant<int, K1>{}, prev);
-                }
-                if (G3_TRACE && HAS_CUR) trace(PP, 1);
-            };
+            }
+            if constexpr (RES && HAS_PREV && PP < 2) {
+                res_request(std::integral_constant<int, K0>{}, prev);
+                res_request(std::integral_constant<int, K1>{}, prev);
+            }
+            if (G3_TRACE && HAS_CUR) trace(PP, 1);
             if (HAS_CUR && !(G3_DBG & 2)) {
-                mma_step(std::integral_constant<int, K0>{}, requests);
-                mma_step(std::integral_constant<int, K1>{}, []() {});
-            } else {
-                requests();
+                mma_group(std::integral_constant<int, K0>{}, std::integral_constant<int, 1>{});
+                mma_group(std::integral_constant<int, K1>{}, std::integral_constant<int, 0>{});
+                mma_group(std::integral_constant<int, K1>{}, std::integral_constant<int, 1>{});
             }
             if constexpr (HAS_PREV && PP >= 1) {
                 if (!(G3_DBG & 4)) {
@@ -825,33 +862,42 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
     };
 
     // ---- the unit stream, two accumulator sets alternating
-    v16i acc0[2][2], acc1[2][2];
-    int u_cur = u_first;
-    auto locate = [&](int u, G3Tile &t) __attribute__((always_inline)) {
-        const int tm = u / p.tiles_n;
+    auto locate = [&](int u, int cb) __attribute__((always_inline)) {
+        GaUnit t;
+        const int tm = u / p.tiles_n, tn = u - tm * p.tiles_n;
         t.row0 = tm << 8;
-        t.col0 = (u - tm * p.tiles_n) << 7;
+        t.col0 = tn << 7;
+        t.cb = cb;
+        t.need_a = (u == u_first || tn == 0) ? 1 : 0;
+        t.valid = u < u_end ? 1 : 0;
+        return t;
     };
-    G3Tile cur{0, 0, 0}, prev{0, 0, 0}, nxt{0, 0, 0};
-    locate(u_cur, cur);
-    locate(u_cur + 1, nxt);
+    int u_cur = u_first;
+    GaUnit cur = locate(u_cur, 0), prev = cur, next = locate(u_cur + 1, 1);
+    // prologue: constants and the slices of pairs 0 and 1 of the first unit
+    set_panel(cur.row0);
+    set_wtile(cur.col0);
+    issue_consts(cur.col0, 0);
+    issue_slice(std::integral_constant<int, 0>{}, cur);
+    issue_slice(std::integral_constant<int, 1>{}, cur);
+    issue_slice(std::integral_constant<int, 2>{}, cur);
+    issue_slice(std::integral_constant<int, 3>{}, cur);
     auto advance = [&]() __attribute__((always_inline)) {
         prev = cur;
+        cur = next;
         ++u_cur;
-        const int par = cur.par == 2 ? 0 : cur.par + 1;
-        cur = nxt;
-        cur.par = par;
-        locate(u_cur + 1, nxt);
-        return u_cur < u_end;
+        next = locate(u_cur + 1, cur.cb == 2 ? 0 : cur.cb + 1);
+        return cur.valid != 0;
     };
+    v16i acc0[2][2], acc1[2][2];
     const std::true_type T{};
     const std::false_type F{};
-    tile_body(T, F, acc0, acc1, cur, prev, u_cur + 1 < u_end, nxt.col0);
+    tile_body(T, F, acc0, acc1, cur, prev, next);
     for (;;) {
-        if (!advance()) { tile_body(F, T, acc1, acc0, cur, prev, false, 0); break; }
-        tile_body(T, T, acc1, acc0, cur, prev, u_cur + 1 < u_end, nxt.col0);
-        if (!advance()) { tile_body(F, T, acc0, acc1, cur, prev, false, 0); break; }
-        tile_body(T, T, acc0, acc1, cur, prev, u_cur + 1 < u_end, nxt.col0);
+        if (!advance()) { tile_body(F, T, acc1, acc0, cur, prev, next); break; }
+        tile_body(T, T, acc1, acc0, cur, prev, next);
+        if (!advance()) { tile_body(F, T, acc0, acc1, cur, prev, next); break; }
+        tile_body(T, T, acc0, acc1, cur, prev, next);
     }
     if (G3_TRACE && bid == 0) {
         __syncthreads();
