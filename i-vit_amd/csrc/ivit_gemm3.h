@@ -546,6 +546,31 @@ __device__ __forceinline__ void ga_swap32(int &a, int &b) {
     b = (int)r[1];
 }
 
+// requant of one quad: four independent cvt -> fma (or mul, add) chains issued abreast.  Left to the compiler the four
+// chains are emitted one after the other through ONE temporary register pair — a dependent cvt/fma/med3 sequence per
+// element, ~2x the issue-bound time (measured on the timeline trace).
+template <bool FMA>
+__device__ __forceinline__ void ga_rq4(const int (&z)[4], double c0, double c1, double c2, double c3, int (&o)[4]) {
+    double t0, t1, t2, t3;
+    const double mg = G3_MAGIC;
+    if (FMA) {
+        asm("v_cvt_f64_i32 %0, %4\n\tv_cvt_f64_i32 %1, %5\n\tv_cvt_f64_i32 %2, %6\n\tv_cvt_f64_i32 %3, %7\n\t"
+            "v_fma_f64 %0, %0, %8, %12\n\tv_fma_f64 %1, %1, %9, %12\n\tv_fma_f64 %2, %2, %10, %12\n\tv_fma_f64 %3, %3, %11, %12"
+            : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+            : "v"(z[0]), "v"(z[1]), "v"(z[2]), "v"(z[3]), "v"(c0), "v"(c1), "v"(c2), "v"(c3), "v"(mg));
+    } else {
+        asm("v_cvt_f64_i32 %0, %4\n\tv_cvt_f64_i32 %1, %5\n\tv_cvt_f64_i32 %2, %6\n\tv_cvt_f64_i32 %3, %7\n\t"
+            "v_mul_f64 %0, %0, %8\n\tv_mul_f64 %1, %1, %9\n\tv_mul_f64 %2, %2, %10\n\tv_mul_f64 %3, %3, %11\n\t"
+            "v_add_f64 %0, %0, %12\n\tv_add_f64 %1, %1, %12\n\tv_add_f64 %2, %2, %12\n\tv_add_f64 %3, %3, %12"
+            : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+            : "v"(z[0]), "v"(z[1]), "v"(z[2]), "v"(z[3]), "v"(c0), "v"(c1), "v"(c2), "v"(c3), "v"(mg));
+    }
+    o[0] = __double2loint(t0);
+    o[1] = __double2loint(t1);
+    o[2] = __double2loint(t2);
+    o[3] = __double2loint(t3);
+}
+
 struct GaUnit {
     int row0, col0;   // first token / channel
     int cb;           // constants buffer (0..2)
@@ -656,104 +681,127 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
                          const GaUnit prev, const GaUnit next) __attribute__((always_inline)) {
         constexpr bool HAS_CUR = decltype(has_cur_t)::value, HAS_PREV = decltype(has_prev_t)::value;
 
-        // ---- epilogue of sub-tile (i, j) of `prev`: requant -> pack -> half-wave exchange -> store
-        auto epi_sub = [&](auto c_t) __attribute__((always_inline)) {
+        // ---- epilogue of `prev`, in pieces small enough to be dealt out between the MFMA groups of a pair.
+        // Sub-tile C = (i = C & 1, j = C >> 1).  int8: four quads (requant + pack) and a finish (half-wave exchange +
+        // one 16-byte store); int16: two pieces (two quads + exchange + residual requant-add + one store each).
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        int dpk[2][4];     // packed dwords of the (up to two) int8 sub-tiles in flight in a pair
+        (void)dpk;
+        auto rq_quad = [&](auto c_t, int g, int (&o)[4]) __attribute__((always_inline)) {
             constexpr int C = decltype(c_t)::value, i = C & 1, j = C >> 1;
-            const v16i &acc = accP[i][j];
+            const unsigned cads = pc_lds + (unsigned)prev.cb * G3_CONST_BYTES + j * 256 + g * 64;
+            const v2d c01 = __builtin_bit_cast(v2d, ga_lds_read16(cads));
+            const v2d c23 = __builtin_bit_cast(v2d, ga_lds_read16(cads + 16));
+            const int z[4] = {accP[i][j][g * 4], accP[i][j][g * 4 + 1], accP[i][j][g * 4 + 2], accP[i][j][g * 4 + 3]};
+            ga_rq4<FMA>(z, c01[0], c01[1], c23[0], c23[1], o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = OUT8 ? min(max(o[e], -128), 127) : min(max(o[e], -32768), 32767);
+        };
+        auto epi8_quad = [&](auto c_t, auto slot_t, int g) __attribute__((always_inline)) {
+            int o[4];
+            rq_quad(c_t, g, o);
+            const unsigned w01 = __builtin_amdgcn_perm((unsigned)o[1], (unsigned)o[0], 0x0c0c0400u);
+            const unsigned w23 = __builtin_amdgcn_perm((unsigned)o[3], (unsigned)o[2], 0x0c0c0400u);
+            dpk[decltype(slot_t)::value][g] = (int)__builtin_amdgcn_perm(w23, w01, 0x05040100u);
+        };
+        auto epi8_finish = [&](auto c_t, auto slot_t) __attribute__((always_inline)) {
+            constexpr int C = decltype(c_t)::value, i = C & 1, j = C >> 1, SL = decltype(slot_t)::value;
             const int grow = sub_row(prev, i), gcol = sub_col(prev, j);
             const bool ok = grow < p.M && gcol < p.N;
-            typedef double v2d __attribute__((ext_vector_type(2)));
-            const unsigned cads = pc_lds + (unsigned)prev.cb * G3_CONST_BYTES + j * 256;
-            // requant of quad g: 4 consecutive channels 8g + 4*half + e
-            auto rq4 = [&](int g, int(&o)[4]) __attribute__((always_inline)) {
-                const v2d c01 = __builtin_bit_cast(v2d, ga_lds_read16(cads + g * 64));
-                const v2d c23 = __builtin_bit_cast(v2d, ga_lds_read16(cads + g * 64 + 16));
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int z = acc[g * 4 + e];
-                    const double c = e < 2 ? c01[e] : c23[e - 2];
-                    const double t = FMA ? __builtin_fma((double)z, c, G3_MAGIC) : ((double)z * c + G3_MAGIC);
-                    const int v = __double2loint(t);
-                    o[e] = OUT8 ? min(max(v, -128), 127) : min(max(v, -32768), 32767);
-                }
-            };
-            if constexpr (OUT8) {
-                int d[4];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    int o[4];
-                    rq4(g, o);
-                    const unsigned w01 = __builtin_amdgcn_perm((unsigned)o[1], (unsigned)o[0], 0x0c0c0400u);
-                    const unsigned w23 = __builtin_amdgcn_perm((unsigned)o[3], (unsigned)o[2], 0x0c0c0400u);
-                    d[g] = (int)__builtin_amdgcn_perm(w23, w01, 0x05040100u);
-                }
-                // lower half-wave: channels 0..15 of the token = {h0.d0, h1.d0, h0.d1, h1.d1}; upper: 16..31
-                ga_swap32(d[0], d[2]);
-                ga_swap32(d[1], d[3]);
-                const v4i v = {d[0], d[2], d[1], d[3]};
-                if (G3_DBG & 8) return;
-                if constexpr (EPI == EPI_RQ8_CH) {
-                    char *dst = ok ? reinterpret_cast<char *>(p.out) + (long long)grow * p.ldc + gcol : dummy;
-                    *reinterpret_cast<v4i *>(dst) = v;
+            // lower half-wave: channels 0..15 of the token = {h0.d0, h1.d0, h0.d1, h1.d1}; upper: 16..31
+            ga_swap32(dpk[SL][0], dpk[SL][2]);
+            ga_swap32(dpk[SL][1], dpk[SL][3]);
+            const v4i v = {dpk[SL][0], dpk[SL][2], dpk[SL][1], dpk[SL][3]};
+            if (G3_DBG & 8) return;
+            if constexpr (EPI == EPI_RQ8_CH) {
+                char *dst = ok ? reinterpret_cast<char *>(p.out) + (long long)grow * p.ldc + gcol : dummy;
+                *reinterpret_cast<v4i *>(dst) = v;
+                issued += 1;
+            } else {
+                // q / k: [b, head, t, dh] — 16 channels of one head; v^T: [b, head, dh, ldv] byte scatter.
+                // The 128-column unit lies inside one of q / k / v and the 32-column group inside one head
+                // (D % 128 == 0, dh % 32 == 0: checked by the host), so which / head are uniform.
+                const int ucol = prev.col0 + wn * 64 + j * 32;
+                const int which = ucol / p.D, within = ucol - which * p.D;
+                const int head = within / p.dh, d0 = within - head * p.dh + half * 16;
+                const int gr = ok ? grow : 0;
+                const int b = g3_div(gr, p.T, rcpT), t = gr - b * p.T;
+                const long long bh = (long long)b * p.H + head;
+                if (which < 2) {
+                    char *dst = reinterpret_cast<char *>(which == 0 ? p.q : p.k) + (bh * p.T + t) * p.dh + d0;
+                    *reinterpret_cast<v4i *>(ok ? dst : dummy) = v;
                     issued += 1;
                 } else {
-                    // q / k: [b, head, t, dh] — 16 channels of one head; v^T: [b, head, dh, ldv] byte scatter.
-                    // The 128-column unit lies inside one of q / k / v and the 32-column group inside one head
-                    // (D % 128 == 0, dh % 32 == 0: checked by the host), so which / head are uniform.
-                    const int ucol = prev.col0 + wn * 64 + j * 32;
-                    const int which = ucol / p.D, within = ucol - which * p.D;
-                    const int head = within / p.dh, d0 = within - head * p.dh + half * 16;
-                    const int gr = ok ? grow : 0;
-                    const int b = g3_div(gr, p.T, rcpT), t = gr - b * p.T;
-                    const long long bh = (long long)b * p.H + head;
-                    if (which < 2) {
-                        char *dst = reinterpret_cast<char *>(which == 0 ? p.q : p.k) + (bh * p.T + t) * p.dh + d0;
-                        *reinterpret_cast<v4i *>(ok ? dst : dummy) = v;
-                        issued += 1;
-                    } else {
-                        char *dst = reinterpret_cast<char *>(p.vt) + (bh * p.dh + d0) * p.ldv + t;
+                    char *dst = reinterpret_cast<char *>(p.vt) + (bh * p.dh + d0) * p.ldv + t;
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            char *d1 = ok ? dst + (long long)e * p.ldv : dummy;
-                            *d1 = (char)(v[e >> 2] >> (8 * (e & 3)));
-                        }
-                        issued += 16;
+                    for (int e = 0; e < 16; ++e) {
+                        char *d1 = ok ? dst + (long long)e * p.ldv : dummy;
+                        *d1 = (char)(v[e >> 2] >> (8 * (e & 3)));
                     }
+                    issued += 16;
+                }
+            }
+        };
+        // int16 piece h2 of sub-tile C: quads g = h2 and h2 + 2.  lower half-wave: channels 8*h2 .. +7 =
+        // {h0.g(h2), h1.g(h2)}; upper half-wave: 16 + the same
+        auto epi16_piece = [&](auto c_t, int h2) __attribute__((always_inline)) {
+            constexpr int C = decltype(c_t)::value, i = C & 1, j = C >> 1;
+            const int grow = sub_row(prev, i), gcol = sub_col(prev, j);
+            const bool ok = grow < p.M && gcol < p.N;
+            char *dst = ok ? reinterpret_cast<char *>(p.out) + ((long long)grow * p.ldc + gcol) * 2 + h2 * 16 : dummy;
+            int w[2][2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                int o[4];
+                rq_quad(c_t, h2 + 2 * q, o);
+                w[q][0] = (int)__builtin_amdgcn_perm((unsigned)o[1], (unsigned)o[0], 0x05040100u);
+                w[q][1] = (int)__builtin_amdgcn_perm((unsigned)o[3], (unsigned)o[2], 0x05040100u);
+            }
+            ga_swap32(w[0][0], w[1][0]);
+            ga_swap32(w[0][1], w[1][1]);
+            v4i v = {w[0][0], w[0][1], w[1][0], w[1][1]};
+            if constexpr (RES) {
+                const v4i rs = h2 ? resv[C * 2 + 1] : resv[C * 2];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int t0 = (int)(short)(v[q] & 0xffff), t1 = v[q] >> 16;
+                    const int r0 = (int)(short)(rs[q] & 0xffff), r1 = rs[q] >> 16;
+                    int o0 = rq_fast(r0, cr) + rq_fast(t0, cm);
+                    int o1 = rq_fast(r1, cr) + rq_fast(t1, cm);
+                    o0 = min(max(o0, -32768), 32767);
+                    o1 = min(max(o1, -32768), 32767);
+                    v[q] = (o0 & 0xffff) | (o1 << 16);
+                }
+            }
+            if (!(G3_DBG & 8)) {
+                *reinterpret_cast<v4i *>(dst) = v;
+                issued += 1;
+            }
+        };
+        // the epilogue work of a pair that finishes sub-tiles X (and Y, if TWO), dealt into three sections
+        auto epi_section = [&](auto x_t, auto y_t, auto two_t, int sec) __attribute__((always_inline)) {
+            constexpr bool TWO = decltype(two_t)::value;
+            const std::integral_constant<int, 0> S0{};
+            const std::integral_constant<int, 1> S1{};
+            if (G3_DBG & 4) return;
+            if constexpr (OUT8) {
+                if (TWO) {
+                    if (sec == 0) { epi8_quad(x_t, S0, 0); epi8_quad(x_t, S0, 1); epi8_quad(x_t, S0, 2); }
+                    if (sec == 1) { epi8_quad(x_t, S0, 3); epi8_finish(x_t, S0); epi8_quad(y_t, S1, 0); epi8_quad(y_t, S1, 1); }
+                    if (sec == 2) { epi8_quad(y_t, S1, 2); epi8_quad(y_t, S1, 3); epi8_finish(y_t, S1); }
+                } else {
+                    if (sec == 0) { epi8_quad(x_t, S0, 0); }
+                    if (sec == 1) { epi8_quad(x_t, S0, 1); epi8_quad(x_t, S0, 2); }
+                    if (sec == 2) { epi8_quad(x_t, S0, 3); epi8_finish(x_t, S0); }
                 }
             } else {
-                // two independent 8-channel pieces per lane: piece h2 pairs the quads g = h2 and g = h2 + 2.
-                // lower half-wave: channels 8*h2 .. +7 = {h0.g(h2), h1.g(h2)}; upper half-wave: 16 + the same
-                char *dst = ok ? reinterpret_cast<char *>(p.out) + ((long long)grow * p.ldc + gcol) * 2 : dummy;
-#pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2) {
-                    int w[2][2];
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        int o[4];
-                        rq4(h2 + 2 * q, o);
-                        w[q][0] = (int)__builtin_amdgcn_perm((unsigned)o[1], (unsigned)o[0], 0x05040100u);
-                        w[q][1] = (int)__builtin_amdgcn_perm((unsigned)o[3], (unsigned)o[2], 0x05040100u);
-                    }
-                    ga_swap32(w[0][0], w[1][0]);
-                    ga_swap32(w[0][1], w[1][1]);
-                    v4i v = {w[0][0], w[0][1], w[1][0], w[1][1]};
-                    if constexpr (RES) {
-                        const v4i rs = resv[C * 2 + h2];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int t0 = (int)(short)(v[q] & 0xffff), t1 = v[q] >> 16;
-                            const int r0 = (int)(short)(rs[q] & 0xffff), r1 = rs[q] >> 16;
-                            int o0 = rq_fast(r0, cr) + rq_fast(t0, cm);
-                            int o1 = rq_fast(r1, cr) + rq_fast(t1, cm);
-                            o0 = min(max(o0, -32768), 32767);
-                            o1 = min(max(o1, -32768), 32767);
-                            v[q] = (o0 & 0xffff) | (o1 << 16);
-                        }
-                    }
-                    if (!(G3_DBG & 8)) {
-                        *reinterpret_cast<v4i *>(ok ? dst + h2 * 16 : dummy) = v;
-                        issued += 1;
-                    }
+                if (TWO) {
+                    if (sec == 0) epi16_piece(x_t, 0);
+                    if (sec == 1) { epi16_piece(x_t, 1); epi16_piece(y_t, 0); }
+                    if (sec == 2) epi16_piece(y_t, 1);
+                } else {
+                    if (sec == 1) epi16_piece(x_t, 0);
+                    if (sec == 2) epi16_piece(x_t, 1);
                 }
             }
         };
@@ -772,17 +820,19 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
             mark_res[C] = issued;
         };
 
-        // 4 MFMAs: columns [32 kk, 32 kk + 32) of k-step KT
-        auto mma_group = [&](auto kt_t, auto kk_t) __attribute__((always_inline)) {
+        // fragments of (k-step KT, 32-column half kk) and the 4 MFMAs that consume them
+        auto frag_load = [&](auto kt_t, auto kk_t, v4i (&a)[2], v4i (&b)[2]) __attribute__((always_inline)) {
             constexpr int KT = decltype(kt_t)::value, kk = decltype(kk_t)::value;
             const unsigned sA = (KT < 4 ? fa_lo[kk] + KT * 16384 : fa_hi[kk] + (KT - 4) * 16384);
             const unsigned sB = fw[kk] + KT * GA_WSTAGE;
-            v4i a[2], b[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 a[i] = ga_lds_read16(sA + i * 2048);
                 b[i] = ga_lds_read16(sB + i * 2048);
             }
+        };
+        auto mma4 = [&](const v4i (&a)[2], const v4i (&b)[2]) __attribute__((always_inline)) {
+            if (G3_DBG & 2) return;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -793,21 +843,33 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
         // ---- one PAIR of k-steps (K0 = 2P, K1 = 2P + 1) behind one barrier.  The barrier publishes the slices of
         // both steps (requested two pairs ago) and frees the ring slots of the previous pair, which this pair's DMA
         // requests refill for the pair after next: slices 4, 5 of this unit (pair 0) or 0..3 of the next (pairs 1, 2).
-        // Everything after the barrier is ONE basic block apart from the uniform tests around the DMA requests.
+        // The pair is four hand-ordered sections (scheduling fences between them, free scheduling inside):
+        //   S0: fragments of group 0 and 1 | 4 MFMAs | DMA requests, residual requests
+        //   S1: fragments of group 2 | 4 MFMAs | epilogue part 0      S2: fragments of group 3 | 4 MFMAs | part 1
+        //   S3: 4 MFMAs | epilogue part 2
+        // so that every MFMA group finds its fragments in registers and every section carries requant work to issue
+        // while its MFMAs run.
         auto kpair = [&](auto p_t) __attribute__((always_inline)) {
             constexpr int PP = decltype(p_t)::value, K0 = 2 * PP, K1 = K0 + 1;
+            // epilogue sub-tiles of `prev` finished in this pair: residual flavour 0,1 | 2,3 in pairs 1 | 2 (their
+            // residual pieces are requested a pair earlier, inside this body); else 0 | 1 | 2,3
+            constexpr int E_LO = RES ? (PP == 0 ? 0 : 2 * PP - 2) : (PP == 2 ? 2 : PP);
+            constexpr int E_N = !HAS_PREV ? 0 : (RES ? (PP == 0 ? 0 : 2) : (PP == 2 ? 2 : 1));
+            const std::integral_constant<int, E_LO> EX{};
+            const std::integral_constant<int, (E_LO + 1) & 3> EY{};
+            const std::integral_constant<bool, E_N == 2> ETWO{};
             {
                 // slices of K1 (requested after K0's) landed; the residual pieces of the sub-tiles finished in this pair;
                 // at pair 0 the unit's constants (requested at pair 2 of the previous unit, AFTER this pair's slices)
                 int n = 1 << 20;
                 if (HAS_CUR) n = issued - mark[K1];
                 if (HAS_CUR && PP == 0) n = min(n, issued - mark_cst);
-                if (RES && HAS_PREV && PP >= 1) n = min(n, issued - mark_res[K1 - 2]);
-                if (HAS_CUR || (RES && HAS_PREV && PP >= 1)) ga_wait_vm(n);
+                if (RES && E_N == 2) n = min(n, issued - mark_res[E_LO + 1]);
+                if (HAS_CUR || (RES && E_N == 2)) ga_wait_vm(n);
                 else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if constexpr (RES && HAS_PREV && PP >= 1)     // tie the residual registers to the wait
-                    asm volatile("" : "+v"(resv[(K0 - 2) * 2]), "+v"(resv[(K0 - 2) * 2 + 1]), "+v"(resv[(K1 - 2) * 2]),
-                                 "+v"(resv[(K1 - 2) * 2 + 1]));
+                if constexpr (RES && E_N == 2)     // tie the residual registers to the wait
+                    asm volatile("" : "+v"(resv[E_LO * 2]), "+v"(resv[E_LO * 2 + 1]), "+v"(resv[E_LO * 2 + 2]),
+                                 "+v"(resv[E_LO * 2 + 3]));
             }
             // lgkmcnt(0) (inside ga_wait_vm): a raw s_barrier does not wait for this wave's own LDS reads
             if (G3_TRACE && HAS_CUR) trace(PP == 0 ? 2 : PP - 1, 3);     // belongs to the previous pair's record
@@ -815,21 +877,28 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
             asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             if (G3_TRACE && HAS_CUR) { if (PP == 0) ++tr_unit; trace(PP, 0); }
-            if (HAS_CUR && PP == 0) {
-                // the accumulators start at the bias (lane: channels 32j + 8g + 4*half + e)
-                const unsigned bads = pb_lds + (unsigned)cur.cb * G3_CONST_BYTES;
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const v4i bv = ga_lds_read16(bads + j * 128 + g * 32);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { accC[0][j][g * 4 + e] = bv[e]; accC[1][j][g * 4 + e] = bv[e]; }
-                    }
-            }
-            if (HAS_CUR && !(G3_DBG & 2)) mma_group(std::integral_constant<int, K0>{}, std::integral_constant<int, 0>{});
-            // DMA requests after the first MFMAs are in the pipe
+            const std::integral_constant<int, K0> k0{};
+            const std::integral_constant<int, K1> k1{};
+            const std::integral_constant<int, 0> h0{};
+            const std::integral_constant<int, 1> h1{};
+            v4i fa0[2], fb0[2], fa1[2], fb1[2];
+            // ---- S0
             if (HAS_CUR) {
+                frag_load(k0, h0, fa0, fb0);
+                frag_load(k0, h1, fa1, fb1);
+                if (PP == 0) {
+                    // the accumulators start at the bias (lane: channels 32j + 8g + 4*half + e)
+                    const unsigned bads = pb_lds + (unsigned)cur.cb * G3_CONST_BYTES;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const v4i bv = ga_lds_read16(bads + j * 128 + g * 32);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { accC[0][j][g * 4 + e] = bv[e]; accC[1][j][g * 4 + e] = bv[e]; }
+                        }
+                }
+                mma4(fa0, fb0);
                 const GaUnit &lu = PP == 0 ? cur : next;
                 if (lu.valid) {
                     if (PP == 1) { set_wtile(lu.col0); if (lu.need_a) set_panel(lu.row0); }
@@ -839,21 +908,23 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
                 }
             }
             if constexpr (RES && HAS_PREV && PP < 2) {
-                res_request(std::integral_constant<int, K0>{}, prev);
-                res_request(std::integral_constant<int, K1>{}, prev);
+                res_request(k0, prev);
+                res_request(k1, prev);
             }
             if (G3_TRACE && HAS_CUR) trace(PP, 1);
-            if (HAS_CUR && !(G3_DBG & 2)) {
-                mma_group(std::integral_constant<int, K0>{}, std::integral_constant<int, 1>{});
-                mma_group(std::integral_constant<int, K1>{}, std::integral_constant<int, 0>{});
-                mma_group(std::integral_constant<int, K1>{}, std::integral_constant<int, 1>{});
-            }
-            if constexpr (HAS_PREV && PP >= 1) {
-                if (!(G3_DBG & 4)) {
-                    epi_sub(std::integral_constant<int, K0 - 2>{});
-                    epi_sub(std::integral_constant<int, K1 - 2>{});
-                }
-            }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- S1
+            if (HAS_CUR) { frag_load(k1, h0, fa0, fb0); mma4(fa1, fb1); }
+            if constexpr (E_N > 0) epi_section(EX, EY, ETWO, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- S2
+            if (HAS_CUR) { frag_load(k1, h1, fa1, fb1); mma4(fa0, fb0); }
+            if constexpr (E_N > 0) epi_section(EX, EY, ETWO, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- S3
+            if (HAS_CUR) mma4(fa1, fb1);
+            if constexpr (E_N > 0) epi_section(EX, EY, ETWO, 2);
             if (G3_TRACE && HAS_CUR) { __builtin_amdgcn_sched_barrier(0); trace(PP, 2); }
         };
         kpair(std::integral_constant<int, 0>{});
