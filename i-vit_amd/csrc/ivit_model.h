@@ -13,6 +13,7 @@ struct ivit_vit_s {
     int T, ld, Kp, num_patches;
     bool fused_attention;
     int8_t *gelu_tab;                 // [depth][65536]
+    std::vector<ivit_linear_plan> plans;   // per block: qkv, proj, fc1, fc2 (frozen QuantLinear plans, ivit_linear_plan_create)
     int max_slices;
     std::vector<ivit_handle> slice_h; // one handle per internal stream
     std::vector<hipStream_t> streams;
@@ -84,7 +85,7 @@ int run_slice(const ivit_vit_s *m, ivit_handle h, const int8_t *images, int B, c
     for (int i = 0; i < c.depth; ++i) {
         const ivit_vit_block &b = m->blocks[i];
         RUN(ivit_layernorm_requant(h, x, M, D, D, b.s_ln1, b.n1_bias_int, b.n1_sc, b.n1_dy, a8));
-        RUN(ivit_linear_i8_qkv(h, a8, b.qkv_w, b.qkv_b, b.qkv_dy, q, k, vt, B, T, H, dh, ld));
+        RUN(ivit_linear_i8_qkv_planned(h, m->plans[4 * i], a8, q, k, vt, B, T, H, dh, ld));
         if (m->fused_attention) {
             if (b.exp_aq)
                 RUN(ivit_attention_fused_lut(h, q, k, vt, b.dy_qk, b.s_softmax, b.exp_aq, b.exp_t, b.exp_cls, b.exp_nc,
@@ -98,12 +99,12 @@ int run_slice(const ivit_vit_s *m, ivit_handle h, const int8_t *images, int B, c
             RUN(ivit_shiftmax(h, s8, (int64_t)B * H * T, T, ld, b.s_softmax, 16, p16, ld));
             RUN(ivit_attn_pv_requant(h, p16, vt, b.dy_pv, ctx8, B, H, T, dh, ld, ld));
         }
-        RUN(ivit_linear_i8_requant_residual(h, ctx8, b.proj_w, b.proj_b, b.proj_dy, b.res1_main, b.res1_res, x, y, M, D, D));
+        RUN(ivit_linear_i8_requant_residual_planned(h, m->plans[4 * i + 1], ctx8, b.res1_main, b.res1_res, x, y, M));
         { int16_t *t = x; x = y; y = t; }
         RUN(ivit_layernorm_requant(h, x, M, D, D, b.s_ln2, b.n2_bias_int, b.n2_sc, b.n2_dy, a8));
-        RUN(ivit_linear_i8_requant(h, a8, b.fc1_w, b.fc1_b, b.fc1_dy, 8, h8, M, Hd, D));
+        RUN(ivit_linear_i8_requant_planned(h, m->plans[4 * i + 2], a8, 8, h8, M));
         RUN(ivit_shiftgelu_requant_lut(h, h8, M, Hd, m->gelu_tab + (size_t)i * 65536, g8));
-        RUN(ivit_linear_i8_requant_residual(h, g8, b.fc2_w, b.fc2_b, b.fc2_dy, b.res2_main, b.res2_res, x, y, M, D, Hd));
+        RUN(ivit_linear_i8_requant_residual_planned(h, m->plans[4 * i + 3], g8, b.res2_main, b.res2_res, x, y, M));
         { int16_t *t = x; x = y; y = t; }
     }
     // final norm on the class-token rows only (row stride T*D), then the head's int32 accumulators
@@ -149,7 +150,19 @@ int ivit_vit_create(ivit_handle h, const ivit_vit_config *cfg, const ivit_vit_pa
     }
     for (int i = 0; i < cfg->depth; ++i) {
         int rc = ivit_shiftgelu_build_table(h, m->blocks[i].s_gelu, m->blocks[i].dy_gelu, m->gelu_tab + (size_t)i * 65536);
-        if (rc != IVIT_OK) { (void)hipFree(m->gelu_tab); delete m; return rc; }
+        if (rc != IVIT_OK) { ivit_vit_destroy(m); return rc; }
+        // frozen QuantLinear plans: per-channel multipliers and the exactness bounds of the pipelined GEMMs
+        const ivit_vit_block &b = m->blocks[i];
+        const int D = cfg->embed_dim, Hd = cfg->hidden_dim;
+        const struct { const int8_t *w; const int32_t *bias; const ivit_dyadic *dy; int N, K; } lin[4] = {
+            {b.qkv_w, b.qkv_b, b.qkv_dy, 3 * D, D}, {b.proj_w, b.proj_b, b.proj_dy, D, D},
+            {b.fc1_w, b.fc1_b, b.fc1_dy, Hd, D}, {b.fc2_w, b.fc2_b, b.fc2_dy, D, Hd}};
+        for (int k = 0; k < 4; ++k) {
+            ivit_linear_plan pl = nullptr;
+            rc = ivit_linear_plan_create(h, lin[k].w, lin[k].bias, lin[k].dy, lin[k].N, lin[k].K, &pl);
+            if (rc != IVIT_OK) { ivit_vit_destroy(m); return rc; }
+            m->plans.push_back(pl);
+        }
     }
     if (max_slices > 1) {
         bool ok = hipEventCreateWithFlags(&m->fork, hipEventDisableTiming) == hipSuccess;
@@ -182,6 +195,7 @@ int ivit_vit_destroy(ivit_vit m) {
     for (auto st : m->streams) (void)hipStreamDestroy(st);
     if (m->fork) (void)hipEventDestroy(m->fork);
     if (m->gelu_tab) (void)hipFree(m->gelu_tab);
+    for (auto pl : m->plans) (void)ivit_linear_plan_destroy(pl);
     delete m;
     return IVIT_OK;
 }
