@@ -625,15 +625,19 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
         w_off = (unsigned)min(col0 + w_row, p.N - 1) * (unsigned)p.ldb + a_c0;      // same chunk swizzle: row = tid >> 2
     };
     const unsigned dma_lane0 = wave * 1024;
-    auto issue_slice = [&](auto s_t, const GaUnit &u) __attribute__((always_inline)) {
+    // K = nrounds * 384: a unit is `nrounds` rounds of 6 k-steps over the same 6 + 6 LDS slots.  With one round the A
+    // slices are stationary (requested only by the first unit of a panel); with more they stream like the weights.
+    const int nrounds = p.K / (64 * GA_NK);
+    auto issue_slice = [&](auto s_t, const GaUnit &u, const int round) __attribute__((always_inline)) {
         constexpr int S = decltype(s_t)::value;
+        const int kb = round * (64 * GA_NK) + S * 64;
         if (!((G3_DBG & 1) && u.row0 + u.col0 != 0)) {
-            if (u.need_a) {
-                ga_dma16(A, a_off0, S * 64, smem_lds + S * 16384 + dma_lane0);
-                ga_dma16(A, a_off1, S * 64, smem_lds + S * 16384 + 8192 + dma_lane0);
+            if (u.need_a || nrounds > 1) {
+                ga_dma16(A, a_off0, kb, smem_lds + S * 16384 + dma_lane0);
+                ga_dma16(A, a_off1, kb, smem_lds + S * 16384 + 8192 + dma_lane0);
                 issued += 2;
             }
-            ga_dma16(B, w_off, S * 64, ring_lds + S * GA_WSTAGE + dma_lane0);
+            ga_dma16(B, w_off, kb, ring_lds + S * GA_WSTAGE + dma_lane0);
             issued += 1;
         }
         mark[S] = issued;
@@ -678,7 +682,7 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
     // ------------------------------------------------------------------------------------------------
     // one unit: K loop of `cur` into accC (HAS_CUR) with the epilogue of `prev` out of accP (HAS_PREV)
     auto tile_body = [&](auto has_cur_t, auto has_prev_t, v16i(&accC)[2][2], v16i(&accP)[2][2], const GaUnit cur,
-                         const GaUnit prev, const GaUnit next) __attribute__((always_inline)) {
+                         const GaUnit prev, const GaUnit next, const int round) __attribute__((always_inline)) {
         constexpr bool HAS_CUR = decltype(has_cur_t)::value, HAS_PREV = decltype(has_prev_t)::value;
 
         // ---- epilogue of `prev`, in pieces small enough to be dealt out between the MFMA groups of a pair.
@@ -863,7 +867,7 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
                 // at pair 0 the unit's constants (requested at pair 2 of the previous unit, AFTER this pair's slices)
                 int n = 1 << 20;
                 if (HAS_CUR) n = issued - mark[K1];
-                if (HAS_CUR && PP == 0) n = min(n, issued - mark_cst);
+                if (HAS_CUR && PP == 0 && round == 0) n = min(n, issued - mark_cst);
                 if (RES && E_N == 2) n = min(n, issued - mark_res[E_LO + 1]);
                 if (HAS_CUR || (RES && E_N == 2)) ga_wait_vm(n);
                 else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -886,7 +890,7 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
             if (HAS_CUR) {
                 frag_load(k0, h0, fa0, fb0);
                 frag_load(k0, h1, fa1, fb1);
-                if (PP == 0) {
+                if (PP == 0 && round == 0) {
                     // the accumulators start at the bias (lane: channels 32j + 8g + 4*half + e)
                     const unsigned bads = pb_lds + (unsigned)cur.cb * G3_CONST_BYTES;
 #pragma unroll
@@ -899,12 +903,16 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
                         }
                 }
                 mma4(fa0, fb0);
-                const GaUnit &lu = PP == 0 ? cur : next;
+                // load target: slices 4, 5 of this round (pair 0), slices 0..3 of the next round or of the next unit
+                const bool last_round = round + 1 == nrounds;
+                const bool to_next = PP != 0 && last_round;
+                const GaUnit &lu = to_next ? next : cur;
+                const int lround = PP == 0 ? round : (last_round ? 0 : round + 1);
                 if (lu.valid) {
-                    if (PP == 1) { set_wtile(lu.col0); if (lu.need_a) set_panel(lu.row0); }
-                    issue_slice(std::integral_constant<int, (K0 + 4) % GA_NK>{}, lu);
-                    issue_slice(std::integral_constant<int, (K1 + 4) % GA_NK>{}, lu);
-                    if (PP == 2) issue_consts(lu.col0, lu.cb);
+                    if (PP == 1 && to_next) { set_wtile(lu.col0); if (lu.need_a || nrounds > 1) set_panel(lu.row0); }
+                    issue_slice(std::integral_constant<int, (K0 + 4) % GA_NK>{}, lu, lround);
+                    issue_slice(std::integral_constant<int, (K1 + 4) % GA_NK>{}, lu, lround);
+                    if (PP == 2 && to_next) issue_consts(lu.col0, lu.cb);
                 }
             }
             if constexpr (RES && HAS_PREV && PP < 2) {
@@ -949,10 +957,10 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
     set_panel(cur.row0);
     set_wtile(cur.col0);
     issue_consts(cur.col0, 0);
-    issue_slice(std::integral_constant<int, 0>{}, cur);
-    issue_slice(std::integral_constant<int, 1>{}, cur);
-    issue_slice(std::integral_constant<int, 2>{}, cur);
-    issue_slice(std::integral_constant<int, 3>{}, cur);
+    issue_slice(std::integral_constant<int, 0>{}, cur, 0);
+    issue_slice(std::integral_constant<int, 1>{}, cur, 0);
+    issue_slice(std::integral_constant<int, 2>{}, cur, 0);
+    issue_slice(std::integral_constant<int, 3>{}, cur, 0);
     auto advance = [&]() __attribute__((always_inline)) {
         prev = cur;
         cur = next;
@@ -963,12 +971,16 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
     v16i acc0[2][2], acc1[2][2];
     const std::true_type T{};
     const std::false_type F{};
-    tile_body(T, F, acc0, acc1, cur, prev, next);
+    // round 0 of a unit carries the previous unit's epilogue; rounds 1.. (K > 384) only multiply
+    tile_body(T, F, acc0, acc1, cur, prev, next, 0);
+    for (int r = 1; r < nrounds; ++r) tile_body(T, F, acc0, acc1, cur, prev, next, r);
     for (;;) {
-        if (!advance()) { tile_body(F, T, acc1, acc0, cur, prev, next); break; }
-        tile_body(T, T, acc1, acc0, cur, prev, next);
-        if (!advance()) { tile_body(F, T, acc0, acc1, cur, prev, next); break; }
-        tile_body(T, T, acc0, acc1, cur, prev, next);
+        if (!advance()) { tile_body(F, T, acc1, acc0, cur, prev, next, 0); break; }
+        tile_body(T, T, acc1, acc0, cur, prev, next, 0);
+        for (int r = 1; r < nrounds; ++r) tile_body(T, F, acc1, acc0, cur, prev, next, r);
+        if (!advance()) { tile_body(F, T, acc0, acc1, cur, prev, next, 0); break; }
+        tile_body(T, T, acc0, acc1, cur, prev, next, 0);
+        for (int r = 1; r < nrounds; ++r) tile_body(T, F, acc0, acc1, cur, prev, next, r);
     }
     if (G3_TRACE && bid == 0) {
         __syncthreads();
