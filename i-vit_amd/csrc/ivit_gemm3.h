@@ -498,9 +498,11 @@ __global__ __launch_bounds__(G3Cfg<ASTAT>::NT, 2) void gemm_ps_kernel(GemmArgs p
 //     (lanes outside the matrix store to a scratch line), the running count lives in SGPRs, and the wait
 //     is picked from a jump table of immediates.  Stores and residual loads therefore never hold up the
 //     operand stream, wherever they are issued.
-#define GA_NK 6
-#define GA_PANEL (GA_NK * 16384)
-#define GA_WSTAGE 8192
+#define GA_NK 3                       // k-steps of 128 columns per round (K = 384 per round)
+#define GA_BK 128
+#define GA_ASLICE 32768               // 256 tokens x 128 B
+#define GA_PANEL (GA_NK * GA_ASLICE)
+#define GA_WSTAGE 16384               // 128 channels x 128 B
 #define GA_RING (GA_NK * GA_WSTAGE)
 #define GA_SMEM (GA_PANEL + GA_RING + 3 * G3_CONST_BYTES)
 // timeline instrumentation (compile time, -DG3_TRACE=1 into a scratch library): wave w of workgroup 0 stamps
@@ -609,36 +611,46 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
 
     // ---- vector-memory bookkeeping (all uniform): `issued` counts this wave's VMEM instructions,
     // mark[k] = count right after the slices of k-step k (ring slot k) were requested
-    int issued = 0, mark[GA_NK] = {0, 0, 0, 0, 0, 0}, mark_res[4] = {0, 0, 0, 0}, mark_cst = 0;
+    int issued = 0, mark[GA_NK] = {0, 0, 0}, mark_res[4] = {0, 0, 0, 0}, mark_cst = 0;
 
-    // ---- operand DMA.  Piece -> (row, 16-byte chunk) as in g2_issue: the LDS image [row][64] is XOR-swizzled through
-    // the SOURCE chunk.  Per-lane byte offsets (relative to A / B) are recomputed once per panel / per unit; a slice
-    // then costs one scalar add for M0 and the instruction itself.
-    const int a_row0 = tid >> 2, a_row1 = (tid + 512) >> 2, w_row = tid >> 2;
-    const int a_c0 = ((tid & 3) ^ ((a_row0 >> 2) & 3)) * 16, a_c1 = ((tid & 3) ^ ((a_row1 >> 2) & 3)) * 16;
-    unsigned a_off0 = 0, a_off1 = 0, w_off = 0;
+    // ---- operand DMA.  A k-step is 128 columns: every row slice is one whole 128-byte line, fetched by 8 lanes
+    // (64-column slices made every line travel L2 -> L1 twice, once per half).  Piece id -> (row = id >> 3, position
+    // id & 7); the LDS image [row][128 B] is lane-linear and XOR-swizzled through the SOURCE chunk
+    // (chunk = position ^ ((row >> 1) & 7): conflict-free ds_read_b128 for the MFMA fragments).  Per-lane byte offsets
+    // (relative to A / B) are recomputed once per panel / per unit; a slice then costs a scalar M0 write and the
+    // instruction itself.
+    unsigned a_off[4] = {0, 0, 0, 0}, w_off[2] = {0, 0};
+    auto piece_chunk = [&](int id) __attribute__((always_inline)) { return (((id & 7) ^ ((id >> 4) & 7)) * 16); };
     auto set_panel = [&](int row0) __attribute__((always_inline)) {
-        a_off0 = (unsigned)min(row0 + a_row0, p.M - 1) * (unsigned)p.lda + a_c0;
-        a_off1 = (unsigned)min(row0 + a_row1, p.M - 1) * (unsigned)p.lda + a_c1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = tid + i * 512;
+            a_off[i] = (unsigned)min(row0 + (id >> 3), p.M - 1) * (unsigned)p.lda + piece_chunk(id);
+        }
     };
     auto set_wtile = [&](int col0) __attribute__((always_inline)) {
-        w_off = (unsigned)min(col0 + w_row, p.N - 1) * (unsigned)p.ldb + a_c0;      // same chunk swizzle: row = tid >> 2
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int id = tid + i * 512;
+            w_off[i] = (unsigned)min(col0 + (id >> 3), p.N - 1) * (unsigned)p.ldb + piece_chunk(id);
+        }
     };
     const unsigned dma_lane0 = wave * 1024;
-    // K = nrounds * 384: a unit is `nrounds` rounds of 6 k-steps over the same 6 + 6 LDS slots.  With one round the A
+    // K = nrounds * 384: a unit is `nrounds` rounds of 3 k-steps over the same 3 + 3 LDS slots.  With one round the A
     // slices are stationary (requested only by the first unit of a panel); with more they stream like the weights.
-    const int nrounds = p.K / (64 * GA_NK);
+    const int nrounds = p.K / (GA_BK * GA_NK);
     auto issue_slice = [&](auto s_t, const GaUnit &u, const int round) __attribute__((always_inline)) {
         constexpr int S = decltype(s_t)::value;
-        const int kb = round * (64 * GA_NK) + S * 64;
+        const int kb = round * (GA_BK * GA_NK) + S * GA_BK;
         if (!((G3_DBG & 1) && u.row0 + u.col0 != 0)) {
             if (u.need_a || nrounds > 1) {
-                ga_dma16(A, a_off0, kb, smem_lds + S * 16384 + dma_lane0);
-                ga_dma16(A, a_off1, kb, smem_lds + S * 16384 + 8192 + dma_lane0);
-                issued += 2;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ga_dma16(A, a_off[i], kb, smem_lds + S * GA_ASLICE + i * 8192 + dma_lane0);
+                issued += 4;
             }
-            ga_dma16(B, w_off, kb, ring_lds + S * GA_WSTAGE + dma_lane0);
-            issued += 1;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) ga_dma16(B, w_off[i], kb, ring_lds + S * GA_WSTAGE + i * 8192 + dma_lane0);
+            issued += 2;
         }
         mark[S] = issued;
     };
@@ -651,13 +663,14 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
     // ---- MFMA fragment / constant addresses.  The LDS image is 148 KB but a DS instruction's immediate offset
     // stops at 64 KB: left alone, the compiler keeps one address register per (k-step, operand).  Opaque per-lane
     // bases reach every fragment with an immediate.
-    unsigned fa_lo[2], fa_hi[2], fw[2];
+    unsigned fa_lo[4], fa_hi[4], fw[4];          // per 32-column group q of a 128-column slice
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-        fa_lo[kk] = smem_lds + lds_off(wm * 64 + (lane & 31), kk * 2 + half);
-        fa_hi[kk] = fa_lo[kk] + 4 * 16384;
-        fw[kk] = ring_lds + lds_off(wn * 64 + (lane & 31), kk * 2 + half);
-        asm volatile("" : "+v"(fa_lo[kk]), "+v"(fa_hi[kk]), "+v"(fw[kk]));
+    for (int q = 0; q < 4; ++q) {
+        const int ra = wm * 64 + (lane & 31), rw = wn * 64 + (lane & 31), ch = q * 2 + half;
+        fa_lo[q] = smem_lds + ra * 128 + ((ch ^ ((ra >> 1) & 7)) << 4);
+        fa_hi[q] = fa_lo[q] + 2 * GA_ASLICE;
+        fw[q] = ring_lds + rw * 128 + ((ch ^ ((rw >> 1) & 7)) << 4);
+        asm volatile("" : "+v"(fa_lo[q]), "+v"(fa_hi[q]), "+v"(fw[q]));
     }
     unsigned pc_lds = cst_lds + (wn * 64 + half * 4) * 8;          // this lane's first multiplier, buffer 0
     unsigned pb_lds = cst_lds + 1024 + (wn * 64 + half * 4) * 4;   // this lane's first bias word, buffer 0
@@ -825,14 +838,14 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
         };
 
         // fragments of (k-step KT, 32-column half kk) and the 4 MFMAs that consume them
-        auto frag_load = [&](auto kt_t, auto kk_t, v4i (&a)[2], v4i (&b)[2]) __attribute__((always_inline)) {
-            constexpr int KT = decltype(kt_t)::value, kk = decltype(kk_t)::value;
-            const unsigned sA = (KT < 4 ? fa_lo[kk] + KT * 16384 : fa_hi[kk] + (KT - 4) * 16384);
-            const unsigned sB = fw[kk] + KT * GA_WSTAGE;
+        auto frag_load = [&](auto kt_t, auto q_t, v4i (&a)[2], v4i (&b)[2]) __attribute__((always_inline)) {
+            constexpr int KT = decltype(kt_t)::value, q = decltype(q_t)::value;
+            const unsigned sA = (KT < 2 ? fa_lo[q] + KT * GA_ASLICE : fa_hi[q]);
+            const unsigned sB = fw[q] + KT * GA_WSTAGE;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                a[i] = ga_lds_read16(sA + i * 2048);
-                b[i] = ga_lds_read16(sB + i * 2048);
+                a[i] = ga_lds_read16(sA + i * 4096);
+                b[i] = ga_lds_read16(sB + i * 4096);
             }
         };
         auto mma4 = [&](const v4i (&a)[2], const v4i (&b)[2]) __attribute__((always_inline)) {
@@ -854,7 +867,7 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
         // so that every MFMA group finds its fragments in registers and every section carries requant work to issue
         // while its MFMAs run.
         auto kpair = [&](auto p_t) __attribute__((always_inline)) {
-            constexpr int PP = decltype(p_t)::value, K0 = 2 * PP, K1 = K0 + 1;
+            constexpr int PP = decltype(p_t)::value;      // k-step (128 columns) of the round
             // epilogue sub-tiles of `prev` finished in this pair: residual flavour 0,1 | 2,3 in pairs 1 | 2 (their
             // residual pieces are requested a pair earlier, inside this body); else 0 | 1 | 2,3
             constexpr int E_LO = RES ? (PP == 0 ? 0 : 2 * PP - 2) : (PP == 2 ? 2 : PP);
@@ -866,7 +879,7 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
                 // slices of K1 (requested after K0's) landed; the residual pieces of the sub-tiles finished in this pair;
                 // at pair 0 the unit's constants (requested at pair 2 of the previous unit, AFTER this pair's slices)
                 int n = 1 << 20;
-                if (HAS_CUR) n = issued - mark[K1];
+                if (HAS_CUR) n = issued - mark[PP];
                 if (HAS_CUR && PP == 0 && round == 0) n = min(n, issued - mark_cst);
                 if (RES && E_N == 2) n = min(n, issued - mark_res[E_LO + 1]);
                 if (HAS_CUR || (RES && E_N == 2)) ga_wait_vm(n);
@@ -881,15 +894,16 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
             asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             if (G3_TRACE && HAS_CUR) { if (PP == 0) ++tr_unit; trace(PP, 0); }
-            const std::integral_constant<int, K0> k0{};
-            const std::integral_constant<int, K1> k1{};
-            const std::integral_constant<int, 0> h0{};
-            const std::integral_constant<int, 1> h1{};
+            const std::integral_constant<int, PP> ks{};
+            const std::integral_constant<int, 0> q0{};
+            const std::integral_constant<int, 1> q1{};
+            const std::integral_constant<int, 2> q2{};
+            const std::integral_constant<int, 3> q3{};
             v4i fa0[2], fb0[2], fa1[2], fb1[2];
             // ---- S0
             if (HAS_CUR) {
-                frag_load(k0, h0, fa0, fb0);
-                frag_load(k0, h1, fa1, fb1);
+                frag_load(ks, q0, fa0, fb0);
+                frag_load(ks, q1, fa1, fb1);
                 if (PP == 0 && round == 0) {
                     // the accumulators start at the bias (lane: channels 32j + 8g + 4*half + e)
                     const unsigned bads = pb_lds + (unsigned)cur.cb * G3_CONST_BYTES;
@@ -910,24 +924,23 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
                 const int lround = PP == 0 ? round : (last_round ? 0 : round + 1);
                 if (lu.valid) {
                     if (PP == 1 && to_next) { set_wtile(lu.col0); if (lu.need_a || nrounds > 1) set_panel(lu.row0); }
-                    issue_slice(std::integral_constant<int, (K0 + 4) % GA_NK>{}, lu, lround);
-                    issue_slice(std::integral_constant<int, (K1 + 4) % GA_NK>{}, lu, lround);
+                    issue_slice(std::integral_constant<int, (PP + 2) % GA_NK>{}, lu, lround);
                     if (PP == 2 && to_next) issue_consts(lu.col0, lu.cb);
                 }
             }
             if constexpr (RES && HAS_PREV && PP < 2) {
-                res_request(k0, prev);
-                res_request(k1, prev);
+                res_request(std::integral_constant<int, 2 * PP>{}, prev);
+                res_request(std::integral_constant<int, 2 * PP + 1>{}, prev);
             }
             if (G3_TRACE && HAS_CUR) trace(PP, 1);
             asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             // ---- S1
-            if (HAS_CUR) { frag_load(k1, h0, fa0, fb0); mma4(fa1, fb1); }
+            if (HAS_CUR) { frag_load(ks, q2, fa0, fb0); mma4(fa1, fb1); }
             if constexpr (E_N > 0) epi_section(EX, EY, ETWO, 0);
             __builtin_amdgcn_sched_barrier(0);
             // ---- S2
-            if (HAS_CUR) { frag_load(k1, h1, fa1, fb1); mma4(fa0, fb0); }
+            if (HAS_CUR) { frag_load(ks, q3, fa1, fb1); mma4(fa0, fb0); }
             if constexpr (E_N > 0) epi_section(EX, EY, ETWO, 1);
             __builtin_amdgcn_sched_barrier(0);
             // ---- S3
@@ -959,8 +972,6 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
     issue_consts(cur.col0, 0);
     issue_slice(std::integral_constant<int, 0>{}, cur, 0);
     issue_slice(std::integral_constant<int, 1>{}, cur, 0);
-    issue_slice(std::integral_constant<int, 2>{}, cur, 0);
-    issue_slice(std::integral_constant<int, 3>{}, cur, 0);
     auto advance = [&]() __attribute__((always_inline)) {
         prev = cur;
         cur = next;
