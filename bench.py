@@ -1,19 +1,26 @@
 #!/usr/bin/env python
-"""bench.py — images/s of the frozen integer DeiT-S forward (batch 256 per GPU, 224x224
-synthetic int8) on N MI355X, one process per GPU, weights broadcast once over RCCL.
+"""bench.py — images/s of the frozen integer ViT / Swin forward on N MI355X, one process per GPU,
+integer constants broadcast once over RCCL (xGMI), images sharded by rank, no per-step collective.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py                                   # DeiT-S b256, 1 GPU (BASELINE.json configs[1])
+    python bench.py --gpus 8 --steps 20 --warmup 3    # launches 8 ranks itself (torch.distributed.run)
+    python bench.py --model {deit_tiny,deit_small,deit_base,swin_tiny,vit_base_384}
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W        # what the driver runs for N > 1
 
-Prints ONE JSON line on rank 0 (contract in the task statement): whole-job images/s,
-`roofline` for the dominant kernel class (int8 MFMA GEMMs, HIP-event timed on the
-launch stream) and `cpu_baseline` (the CPU oracle port timed on the host cores).
-A "step" = one forward of the hot path over one resident batch.
+Prints ONE JSON line on rank 0 (contract in the task statement).  A "step" = one forward of the hot path
+over one resident per-GPU batch.  The timed region (K steps between barriers, max over ranks) is repeated
+`--reps` times; `value` is the MEDIAN repetition (all repetitions are listed) so that one cold burst is not
+the headline.  `roofline`: the int8 MFMA GEMM class and the HBM-bound operators, each timed with HIP events
+on the launch stream while the same forward is issued ONE C-ABI CALL PER OPERATOR on a single stream
+(`timed_on`), which is not the sliced / hipGraph path that produced `value`.  `cpu_baseline`: the CPU
+oracle port on the host cores (N = 1 only).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,11 +30,20 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 INT8_PEAK_TOPS = 5033.0   # 256 CU x 4 SIMD x 2048 OP/clk x 2.4 GHz (dense; = 2x bf16 peak)
-HBM_PEAK_GBS = 8000.0
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 achievable)
+
+# model -> (family, golden fixture, images per GPU of the BASELINE.json config, which config)
+WORKLOADS = {
+    "deit_tiny": ("vit", "deit_tiny_b1.npz", 1, "configs[0]: DeiT-T b1 plumbing baseline"),
+    "deit_small": ("vit", "deit_small_b4.npz", 256, "configs[1]: DeiT-S b256 on one GPU"),
+    "deit_base": ("vit", "deit_base_b2.npz", 64, "configs[2]: DeiT-B b512 over 8 GPUs = 64 per GPU"),
+    "swin_tiny": ("swin", "swin_tiny_b1.npz", 256, "configs[3]: Swin-T b256 on one GPU"),
+    "vit_base_384": ("vit", "vit_base_384_b1.npz", 128, "configs[4]: ViT-B@384 b1024 over 8 GPUs = 128 per GPU"),
+}
 
 
-def model_ops_per_image(cfg):
-    """algorithmic int8 OPs (2 x MAC) per image, SURVEY.md §8(d)."""
+def vit_ops_per_image(cfg):
+    """algorithmic int8 OPs (2 x MAC) per image, SURVEY.md §8(d): (linear, bmm)."""
     T, D, H, dh, Hd = cfg.num_tokens, cfg.embed_dim, cfg.num_heads, cfg.head_dim, cfg.hidden_dim
     Kp = cfg.in_chans * cfg.patch_size ** 2
     lin = cfg.num_patches * Kp * D + cfg.depth * T * (3 * D * D + D * D + 2 * D * Hd) + D * cfg.num_classes
@@ -35,9 +51,25 @@ def model_ops_per_image(cfg):
     return 2 * lin, 2 * bmm
 
 
+def swin_ops_per_image(cfg):
+    """Swin: linear layers + patch merging + windowed attention (49-token windows)."""
+    lin = cfg.grid ** 2 * cfg.in_chans * cfg.patch_size ** 2 * cfg.embed_dim
+    bmm = 0
+    res, C = cfg.grid, cfg.embed_dim
+    for li, depth in enumerate(cfg.depths):
+        L, heads = res * res, cfg.num_heads[li]
+        lin += depth * L * (3 * C * C + C * C + 2 * C * cfg.mlp_ratio * C)
+        bmm += depth * 2 * (L // cfg.window_size ** 2) * heads * (cfg.window_size ** 2) ** 2 * (C // heads)
+        if li < len(cfg.depths) - 1:
+            lin += (L // 4) * 4 * C * 2 * C
+            res, C = res // 2, C * 2
+    lin += C * cfg.num_classes
+    return 2 * lin, 2 * bmm
+
+
 class EventTimer:
-    """Brackets every C-ABI call with HIP events on the launch stream (torch.cuda.Event
-    records on torch's current stream = the stream the handle launches on)."""
+    """Brackets every C-ABI call with HIP events on the launch stream (torch.cuda.Event records on torch's
+    current stream = the stream the handle launches on)."""
 
     def __init__(self, handle, torch):
         self.h, self.torch = handle, torch
@@ -51,7 +83,7 @@ class EventTimer:
             a.record()
             self._orig(name, *args)
             b.record()
-            self.records.append((name, args, a, b))
+            self.records.append((name, a, b))
         self.h.call = call
         return self
 
@@ -61,7 +93,7 @@ class EventTimer:
     def summary(self):
         self.torch.cuda.synchronize()
         out = {}
-        for name, args, a, b in self.records:
+        for name, a, b in self.records:
             d = out.setdefault(name, [0.0, 0])
             d[0] += a.elapsed_time(b)
             d[1] += 1
@@ -77,12 +109,12 @@ def pmc_traffic():
         return None
 
 
-def cpu_baseline(cfg, weights, scales, target_seconds=15.0):
-    """CPU oracle (port of the reference algorithm, OpenMP over the host cores) on a
-    bounded sample of the same workload."""
+def cpu_baseline(family, cfg, weights, scales, target_seconds=15.0):
+    """CPU oracle (port of the reference algorithm, OpenMP over the host cores) on a bounded sample of the
+    same workload."""
     from oracle import oracle as orc
     import ivit_amd as iv
-    o = orc.OracleViT(cfg, weights, scales)
+    o = orc.OracleViT(cfg, weights, scales) if family == "vit" else orc.OracleSwin(cfg, weights, scales)
     cores = os.cpu_count() or 1
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
     imgs = iv.make_images_int8(cfg, 2, seed=1)
@@ -98,33 +130,54 @@ def cpu_baseline(cfg, weights, scales, target_seconds=15.0):
             "sample": f"{n} images of the same {cfg.name} int8 forward, oracle/ivit_oracle.c (OpenMP, {cores} threads), {dt:.1f} s"}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` outside a launcher: start N ranks (one per GPU) and relay rank 0's line."""
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but this node exposes {have} HIP device(s)")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--model", default="deit_small")
-    ap.add_argument("--batch", type=int, default=256, help="images per GPU")
+    ap.add_argument("--reps", type=int, default=3, help="repetitions of the K-step timed region (value = median)")
+    ap.add_argument("--model", default="deit_small", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="images per GPU (default: the BASELINE.json config's share)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=2)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("IVIT_STREAMS", "4")),
-                    help="batch slices on the runner's internal HIP streams (VALU/MFMA overlap)")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("IVIT_STREAMS", "0")),
+                    help="batch slices on the runner's internal HIP streams (0 = per-model default)")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("IVIT_GRAPH", "1")), help="replay a captured hipGraph")
     args = ap.parse_args()
+
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        self_launch(args)
 
     import torch
     import torch.distributed as dist
     import ivit_amd as iv
-    from ivit_amd.engine import ViTEngine, pack_constants
     from ivit_amd import dist as ivdist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    world = int(world_env or "1")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
+    if torch.cuda.device_count() < world and os.environ.get("IVIT_DIST_BACKEND", "nccl") == "nccl":
+        raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} HIP device(s)")
     local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
@@ -133,18 +186,29 @@ def main():
         # "nccl" is RCCL on ROCm; IVIT_DIST_BACKEND=gloo only for single-GPU plumbing tests
         dist.init_process_group(os.environ.get("IVIT_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
 
-    cfg = iv.CONFIGS[args.model]
-    gname = {"deit_small": "deit_small_b4.npz", "deit_tiny": "deit_tiny_b1.npz"}[args.model]
+    family, gname, cfg_batch, which = WORKLOADS[args.model]
+    batch = args.batch or cfg_batch
+    streams = args.streams or {"deit_tiny": 1, "deit_small": 2, "deit_base": 2, "swin_tiny": 4, "vit_base_384": 2}[args.model]
+    streams = max(1, min(streams, batch))
+    cfg = iv.CONFIGS[args.model] if family == "vit" else iv.SWIN_CONFIGS[args.model]
     g = np.load(os.path.join(ROOT, "tests", "golden", gname))
     scales = {k[len("scale/"):]: np.float32(g[k]) for k in g.files if k.startswith("scale/")}
     weights = None
     if rank == 0:
-        weights = iv.make_vit_weights(cfg, int(g["seed"]))
+        weights = (iv.make_vit_weights if family == "vit" else iv.make_swin_weights)(cfg, int(g["seed"]))
     # rank 0 freezes; the packed integer constants travel once over RCCL (xGMI)
-    eng = ivdist.build_engine_broadcast(cfg, weights, scales, device, rank, world)
+    if family == "vit":
+        eng = ivdist.build_engine_broadcast(cfg, weights, scales, device, rank, world)
+    else:
+        eng = ivdist.build_swin_engine_broadcast(cfg, weights, scales, device, rank, world)
 
-    # per-GPU batch is fixed (weak scaling); every rank owns different images
-    imgs = torch.from_numpy(iv.make_images_int8(cfg, args.batch, seed=1 + rank)).to(device)
+    # per-GPU batch is fixed (weak scaling); every rank owns different images.  Rank 0's batch starts with the
+    # golden images so the run carries its own parity guard.
+    gb = int(g["batch"])
+    host_imgs = iv.make_images_int8(cfg, batch, seed=101 + rank)
+    if rank == 0:
+        host_imgs = np.concatenate([iv.make_images_int8(cfg, gb, int(g["images_seed"])), host_imgs])[:batch]
+    imgs = torch.from_numpy(np.ascontiguousarray(host_imgs)).to(device)
 
     def barrier():
         if world > 1:
@@ -152,74 +216,103 @@ def main():
         torch.cuda.synchronize()
 
     if args.graph:
-        step = eng.capture(imgs, args.streams)
+        step = eng.capture(imgs, streams)
     else:
-        step = lambda: eng.forward(imgs, nslices=args.streams)
+        step = lambda: eng.forward(imgs, nslices=streams)
     for _ in range(args.warmup):
         step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    rep_dt = []
+    for _ in range(max(1, args.reps)):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        rep_dt.append(dt)
+    dt = sorted(rep_dt)[len(rep_dt) // 2]
     ms_per_step = dt / args.steps * 1e3
-    value = args.batch * world * args.steps / dt
+    value = batch * world * args.steps / dt
 
-    # parity guard inside the bench: first 4 images of rank 0 are the golden batch
+    # parity guard inside the bench: the first images of rank 0 are the golden batch
     ok = None
-    if rank == 0 and args.model == "deit_small" and args.batch >= 4:
-        logits = step()[:4].cpu().numpy()
-        ok = bool(np.array_equal(logits, g["logits_int"]))
+    if rank == 0 and batch >= gb:
+        ok = bool(np.array_equal(step()[:gb].cpu().numpy(), g["logits_int"]))
 
-    # per-kernel HIP-event timing (separate instrumented steps, same stream)
+    # per-operator HIP-event timing (separate instrumented steps, one stream, one C-ABI call per operator)
     per = {}
     if rank == 0 and args.profile_steps > 0:
+        eng.forward_ops(imgs)
         with EventTimer(eng.h, torch) as et:
             for _ in range(args.profile_steps):
-                eng.forward_ops(imgs)      # same kernels, one C-ABI call per operator
+                eng.forward_ops(imgs)
             per = et.summary()
     if rank == 0:
-        lin_ops, bmm_ops = model_ops_per_image(cfg)
-        gemm_names = ["ivit_linear_i8_requant", "ivit_linear_i8_qkv", "ivit_linear_i8_requant_residual",
-                      "ivit_linear_i8"]
-        g_ms = sum(per.get(n, [0, 0])[0] for n in gemm_names) / max(args.profile_steps, 1)
-        g_n = sum(per.get(n, [0, 0])[1] for n in gemm_names) / max(args.profile_steps, 1)
-        achieved = (lin_ops * args.batch / (g_ms * 1e-3) / 1e12) if g_ms > 0 else None
+        ps = max(args.profile_steps, 1)
+        lin_ops, bmm_ops = (vit_ops_per_image if family == "vit" else swin_ops_per_image)(cfg)
+        is_gemm = lambda n: n.startswith("ivit_linear_i8") or n == "ivit_mlp_fused"
+        g_ms = sum(v[0] for n, v in per.items() if is_gemm(n)) / ps
+        g_n = sum(v[1] for n, v in per.items() if is_gemm(n)) / ps
+        achieved = (lin_ops * batch / (g_ms * 1e-3) / 1e12) if g_ms > 0 else None
+
+        def hbm(name, nbytes):
+            """achieved HBM GB/s of one HBM-bound operator class: algorithmic bytes / HIP-event time"""
+            if name not in per or per[name][0] <= 0:
+                return None
+            ms = per[name][0] / ps
+            gbs = nbytes / (ms * 1e-3) / 1e9
+            return {"ms_per_step": round(ms, 4), "launches": per[name][1] // ps, "algorithmic_bytes_per_step": int(nbytes),
+                    "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
+        hbm_ops = {}
+        if family == "vit":
+            T, D, H, dh, Hd = cfg.num_tokens, cfg.embed_dim, cfg.num_heads, cfg.head_dim, cfg.hidden_dim
+            M = batch * T
+            # SURVEY.md §8(d): LayerNorm + requant int16 -> int8 3 B/elem; ShiftGELU + requant int8 -> int8 2 B/elem;
+            # fused attention reads q, k, v and writes ctx: 4 B per (token, channel)
+            hbm_ops["layernorm_requant"] = hbm("ivit_layernorm_requant", (2 * cfg.depth * M + batch) * D * 3)
+            hbm_ops["shiftgelu_requant"] = hbm("ivit_shiftgelu_requant_lut", cfg.depth * M * Hd * 2)
+            att = "ivit_attention_fused_lut" if "ivit_attention_fused_lut" in per else "ivit_attention_fused"
+            hbm_ops["attention_fused"] = hbm(att, cfg.depth * M * D * 4)
         roofline = {
-            "kernel": "gemm_glds_kernel (QuantLinear GEMMs with fused requant epilogues: patch-embed, qkv, proj, fc1, fc2) + head",
+            "kernel": "QuantLinear GEMM class (gemm_as_kernel / gemm_ps_kernel / gemm_glds_kernel: patch-embed, qkv, proj, fc1, fc2, head; "
+                      "fused requant epilogues)",
             "bound": "mfma", "achieved": None if achieved is None else round(achieved, 1),
             "peak": INT8_PEAK_TOPS, "unit": "TOP/s",
             "frac": None if achieved is None else round(achieved / INT8_PEAK_TOPS, 4),
-            "traffic": pmc_traffic(),
+            "traffic": pmc_traffic() if args.model == "deit_small" else None,
             "launches_per_step": g_n, "ms_per_step_in_kernel": round(g_ms, 4),
             "avg_launch_ms": round(g_ms / g_n, 5) if g_n else None,
-            "algorithmic_ops_per_step": lin_ops * args.batch,
+            "algorithmic_ops_per_step": lin_ops * batch,
             "mfma_ubench_ceiling_tops_random_operands": 3400.0,   # tools/ubench/mfma_peak.hip, profiles/README.md
+            "timed_on": "single stream, one C-ABI call per operator (engine.forward_ops), HIP events on the launch stream — "
+                        "not the sliced / hipGraph path that produced `value`",
+            "hbm_bound_operators": hbm_ops,
         }
-        breakdown = {n: {"ms_per_step": round(v[0] / args.profile_steps, 4), "launches": v[1] // args.profile_steps}
+        breakdown = {n: {"ms_per_step": round(v[0] / ps, 4), "launches": v[1] // ps}
                      for n, v in sorted(per.items(), key=lambda kv: -kv[1][0])}
         out = {
             "metric": "images/sec + int8-MFMA-roofline% for DeiT-S bs256@224 on 1/2/4/8 MI355X",
             "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "int8", "data": "synthetic",
-            "config": {"workload": f"{cfg.name} int8 forward, batch {args.batch}/GPU, {cfg.img_size}x{cfg.img_size}x3 synthetic int8 "
-                                   f"(BASELINE.json configs[1]); weights seeded synthetic, activation scales from the reference calibration",
-                       "global_batch": args.batch * world, "parallelism": f"dp{world} (batch-sharded, weights RCCL-broadcast once)",
-                       "streams_per_gpu": args.streams, "hipgraph": bool(args.graph)},
-            "model_int8_tops": round((lin_ops + bmm_ops) * args.batch * world / (ms_per_step * 1e-3) / 1e12, 1),
-            "model_roofline_frac": round((lin_ops + bmm_ops) * args.batch / (ms_per_step * 1e-3) / 1e12 / INT8_PEAK_TOPS, 4),
+            "config": {"workload": f"{cfg.name} int8 forward, batch {batch}/GPU, {cfg.img_size}x{cfg.img_size}x3 synthetic int8 "
+                                   f"(BASELINE.json {which}); weights seeded synthetic, activation scales from the reference calibration",
+                       "global_batch": batch * world, "parallelism": f"dp{world} (batch-sharded, weights RCCL-broadcast once)",
+                       "streams_per_gpu": streams, "hipgraph": bool(args.graph)},
+            "repetitions_ms_per_step": [round(d / args.steps * 1e3, 4) for d in rep_dt],
+            "value_is": "median repetition",
+            "model_int8_tops": round((lin_ops + bmm_ops) * batch * world / (ms_per_step * 1e-3) / 1e12, 1),
+            "model_roofline_frac": round((lin_ops + bmm_ops) * batch / (ms_per_step * 1e-3) / 1e12 / INT8_PEAK_TOPS, 4),
             "bit_exact_vs_reference_golden": ok,
             "roofline": roofline,
             "kernel_breakdown_ms": breakdown,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, weights, scales)
+            out["cpu_baseline"] = cpu_baseline(family, cfg, weights, scales)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -20,7 +20,9 @@ struct ivit_ctx {
     char err[256];
 };
 
-#define CHECK_H(h) do { if (!(h)) return IVIT_ERR_INVALID; } while (0)
+// every entry point binds the calling thread to the handle's device first: one process may drive several GPUs
+// through several handles
+#define CHECK_H(h) do { if (!(h)) return IVIT_ERR_INVALID; if (hipSetDevice((h)->device) != hipSuccess) return IVIT_ERR_HIP; } while (0)
 #define REQUIRE(h, cond, msg) do { if (!(cond)) { snprintf((h)->err, sizeof((h)->err), "%s: %s", __func__, msg); return IVIT_ERR_INVALID; } } while (0)
 #define LAUNCH_CHECK(h) do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { snprintf((h)->err, sizeof((h)->err), "%s: %s", __func__, hipGetErrorString(e_)); return IVIT_ERR_HIP; } } while (0)
 
@@ -44,7 +46,8 @@ int ivit_create(ivit_handle *out, int device, void *hip_stream) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return IVIT_ERR_NO_DEVICE;
     if (hipSetDevice(device) != hipSuccess) return IVIT_ERR_HIP;
-    ivit_ctx *c = new ivit_ctx();
+    ivit_ctx *c = new (std::nothrow) ivit_ctx();
+    if (!c) return IVIT_ERR_HIP;
     c->device = device;
     c->stream = (hipStream_t)hip_stream;
     c->err[0] = 0;

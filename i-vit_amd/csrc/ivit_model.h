@@ -127,7 +127,8 @@ int ivit_vit_create(ivit_handle h, const ivit_vit_config *cfg, const ivit_vit_pa
                    cfg->num_classes > 0 && cfg->in_chans > 0,
             "bad model configuration");
     REQUIRE(h, max_slices >= 1 && max_slices <= 16, "max_slices must be in [1, 16]");
-    ivit_vit_s *m = new ivit_vit_s();
+    ivit_vit_s *m = new (std::nothrow) ivit_vit_s();
+    if (!m) return IVIT_ERR_HIP;
     m->h = h;
     m->cfg = *cfg;
     m->prm = *params;
@@ -269,7 +270,8 @@ int ivit_vit_graph_create(ivit_vit m, const int8_t *images, int batch, int nslic
     hipGraphExec_t exec = nullptr;
     e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     if (e != hipSuccess) { (void)hipGraphDestroy(graph); snprintf(h->err, sizeof(h->err), "instantiate: %s", hipGetErrorString(e)); return IVIT_ERR_HIP; }
-    ivit_graph_s *g = new ivit_graph_s();
+    ivit_graph_s *g = new (std::nothrow) ivit_graph_s();
+    if (!g) { (void)hipGraphExecDestroy(exec); (void)hipGraphDestroy(graph); return IVIT_ERR_HIP; }
     g->h = h; g->graph = graph; g->exec = exec;
     *out = g;
     return IVIT_OK;
@@ -438,7 +440,8 @@ int ivit_swin_create(ivit_handle h, const ivit_swin_config *cfg, const ivit_swin
     const int grid = cfg->img_size / cfg->patch_size;
     REQUIRE(h, (grid >> (cfg->num_layers - 1)) % 7 == 0 && grid % (7 << (cfg->num_layers - 1)) == 0,
             "every stage resolution must be a multiple of the window");
-    ivit_swin_s *m = new ivit_swin_s();
+    ivit_swin_s *m = new (std::nothrow) ivit_swin_s();
+    if (!m) return IVIT_ERR_HIP;
     m->h = h; m->cfg = *cfg; m->prm = *params;
     m->blocks.assign(params->blocks_host, params->blocks_host + nb);
     if (cfg->num_layers > 1) m->merges.assign(params->merges_host, params->merges_host + cfg->num_layers - 1);
@@ -531,7 +534,8 @@ int ivit_swin_graph_create(ivit_swin m, const int8_t *images, int batch, int nsl
     hipGraphExec_t exec = nullptr;
     e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     if (e != hipSuccess) { (void)hipGraphDestroy(graph); snprintf(h->err, sizeof(h->err), "instantiate: %s", hipGetErrorString(e)); return IVIT_ERR_HIP; }
-    ivit_graph_s *g = new ivit_graph_s();
+    ivit_graph_s *g = new (std::nothrow) ivit_graph_s();
+    if (!g) { (void)hipGraphExecDestroy(exec); (void)hipGraphDestroy(graph); return IVIT_ERR_HIP; }
     g->h = h; g->graph = graph; g->exec = exec;
     *out = g;
     return IVIT_OK;

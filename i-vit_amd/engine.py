@@ -73,7 +73,8 @@ class ViTEngine:
                 self.host[k] = hb[o:o + 16].view(np.float64).reshape(1, 2).copy()
             elif k.endswith("exp_meta"):
                 self.host[k] = hb[o:o + 12].view(np.int32).copy()
-        self.h = _lib.Handle(self.device.index or 0, torch.cuda.current_stream(self.device).cuda_stream)
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.h = _lib.Handle(dev_index, torch.cuda.current_stream(self.device).cuda_stream)
         self._ws = {}
         self.fused_attention = (cfg.head_dim == 64 and cfg.num_tokens <= 640)
         self.use_exp_tables = True      # forward_ops only: False issues the arithmetic Shiftmax (cross-check)
@@ -84,9 +85,17 @@ class ViTEngine:
             self.h.call("ivit_shiftgelu_build_table", self.f32[p + "mlp.s_gelu"], _dy(self.host[p + "mlp.dy_gelu"]),
                         _P(self.gelu_tab[i].data_ptr()))
 
+        self._plans = {}
         self._build_native()
 
     MAX_SLICES = 8
+
+    def plan(self, prefix, N, K):
+        """frozen-QuantLinear plan (ivit_linear_plan_create) of the layer `prefix` — built once, used by forward_ops;
+        the native runner holds its own."""
+        if prefix not in self._plans:
+            self._plans[prefix] = self.h.linear_plan(self.ptr(prefix + ".w"), self.ptr(prefix + ".b"), self.ptr(prefix + ".dy"), N, K)
+        return self._plans[prefix].p
 
     def _build_native(self):
         """ivit_vit_create: hand the runner device pointers into the blob + host scalars."""
@@ -128,6 +137,8 @@ class ViTEngine:
             if getattr(self, "model", None):
                 self.h.lib.ivit_vit_destroy(self.model)
                 self.model = None
+            for pl in getattr(self, "_plans", {}).values():
+                pl.close()
         except Exception:
             pass
 
@@ -249,8 +260,8 @@ class ViTEngine:
             p = f"blocks.{i}."
             call("ivit_layernorm_requant", P(x), M, D, D, f32[p + "ln1.s"], self.ptr(p + "norm1.bias_int"),
                  self.ptr(p + "norm1.sc"), self.ptr(p + "norm1.dy"), P(ws["a8"]))
-            call("ivit_linear_i8_qkv", P(ws["a8"]), self.ptr(p + "attn.qkv.w"), self.ptr(p + "attn.qkv.b"),
-                 self.ptr(p + "attn.qkv.dy"), P(ws["q"]), P(ws["k"]), P(ws["vt"]), B, T, H, dh, ld)
+            call("ivit_linear_i8_qkv_planned", self.plan(p + "attn.qkv", 3 * D, D), P(ws["a8"]), P(ws["q"]), P(ws["k"]),
+                 P(ws["vt"]), B, T, H, dh, ld)
             if self.fused_attention:
                 if p + "attn.exp_meta" in hc and self.use_exp_tables:
                     meta = hc[p + "attn.exp_meta"]
@@ -267,18 +278,15 @@ class ViTEngine:
                 call("ivit_shiftmax", P(ws["s8"]), B * H * T, T, ld, f32[p + "attn.s_softmax"], 16, P(ws["p16"]), ld)
                 call("ivit_attn_pv_requant", P(ws["p16"]), P(ws["vt"]), _dy(hc[p + "attn.dy_pv"]), P(ws["ctx8"]),
                      B, H, T, dh, ld, ld)
-            call("ivit_linear_i8_requant_residual", P(ws["ctx8"]), self.ptr(p + "attn.proj.w"),
-                 self.ptr(p + "attn.proj.b"), self.ptr(p + "attn.proj.dy"), _dy(hc[p + "res1.dy_main"]),
-                 _dy(hc[p + "res1.dy_res"]), P(x), P(y), M, D, D)
+            call("ivit_linear_i8_requant_residual_planned", self.plan(p + "attn.proj", D, D), P(ws["ctx8"]),
+                 _dy(hc[p + "res1.dy_main"]), _dy(hc[p + "res1.dy_res"]), P(x), P(y), M)
             x, y = y, x
             call("ivit_layernorm_requant", P(x), M, D, D, f32[p + "ln2.s"], self.ptr(p + "norm2.bias_int"),
                  self.ptr(p + "norm2.sc"), self.ptr(p + "norm2.dy"), P(ws["a8"]))
-            call("ivit_linear_i8_requant", P(ws["a8"]), self.ptr(p + "mlp.fc1.w"), self.ptr(p + "mlp.fc1.b"),
-                 self.ptr(p + "mlp.fc1.dy"), 8, P(ws["h8"]), M, Hd, D)
+            call("ivit_linear_i8_requant_planned", self.plan(p + "mlp.fc1", Hd, D), P(ws["a8"]), 8, P(ws["h8"]), M)
             call("ivit_shiftgelu_requant_lut", P(ws["h8"]), M, Hd, _P(self.gelu_tab[i].data_ptr()), P(ws["g8"]))
-            call("ivit_linear_i8_requant_residual", P(ws["g8"]), self.ptr(p + "mlp.fc2.w"),
-                 self.ptr(p + "mlp.fc2.b"), self.ptr(p + "mlp.fc2.dy"), _dy(hc[p + "res2.dy_main"]),
-                 _dy(hc[p + "res2.dy_res"]), P(x), P(y), M, D, Hd)
+            call("ivit_linear_i8_requant_residual_planned", self.plan(p + "mlp.fc2", D, Hd), P(ws["g8"]),
+                 _dy(hc[p + "res2.dy_main"]), _dy(hc[p + "res2.dy_res"]), P(x), P(y), M)
             x, y = y, x
         # final norm on the class-token rows only (row stride T*D)
         call("ivit_layernorm_requant", P(x), B, D, T * D, f32["ln.s"], self.ptr("norm.bias_int"),

@@ -102,3 +102,68 @@ def test_shard_range_covers_batch():
             assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in parts]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _shard_forward_worker(rank, world, port, q):
+    """every rank: receive the broadcast constants' source (scales + seeded weights are rank-0 state), run the CPU
+    oracle on ITS shard of the batch, gather the logits."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as orc
+    g = load_golden("micro_vit_b2.npz")
+    cfg = iv.CONFIGS[str(g["cfg_name"])]
+    # rank 0 owns weights and scales; the others get them through the collective (as the constants blob travels)
+    payload = [None]
+    if rank == 0:
+        payload = [(iv.make_vit_weights(cfg, int(g["seed"])), golden_scales(g))]
+    dist.broadcast_object_list(payload, src=0)
+    weights, scales = payload[0]
+    total = 5                                   # ragged on purpose: shards of 3 and 2
+    images = iv.make_images_int8(cfg, total, seed=11)
+    lo, hi = ivdist.shard_range(total, rank, world)
+    logits, _ = orc.OracleViT(cfg, weights, scales).forward(images[lo:hi])
+    mine = torch.zeros(3, cfg.num_classes, dtype=torch.int32)       # padded to the largest shard
+    mine[:hi - lo] = torch.from_numpy(np.asarray(logits, dtype=np.int32))
+    gathered = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    if rank == 0:
+        parts = []
+        for r in range(world):
+            a, b = ivdist.shard_range(total, r, world)
+            parts.append(gathered[r][:b - a].numpy())
+        full, _ = orc.OracleViT(cfg, weights, scales).forward(images)
+        q.put(bool(np.array_equal(np.concatenate(parts), np.asarray(full, dtype=np.int32))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_forward_equals_unsharded_world2():
+    """SURVEY §4 multi-GPU row: two shards run independently (no per-step collective), the gathered logits are the
+    single-process result bit for bit."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shard_forward_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    ok = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok
+
+
+def test_bench_refuses_missing_devices():
+    """`python bench.py --gpus 2` without a launcher starts the ranks itself and fails loudly when the node has fewer
+    devices — it must never report a 1-GPU number as n_gpus: 2."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        return
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0
+    assert "--gpus 2" in (r.stderr + r.stdout)

@@ -747,3 +747,115 @@ def test_attention_shiftmax_tables_equal_arithmetic(H, scale):
                P(dev(tabs["cls"])), int(tabs["NC"]), int(tabs["t"].size), int(tabs["dmin"]), dyv(dpv), P(o2), B, Hh, T, dh, ld)
         assert np.array_equal(o1.cpu().numpy(), o2.cpu().numpy()), (scale, T)
         assert len(np.unique(o1.cpu().numpy())) > 20
+
+
+# ---------------------------------------------------------------- persistent pipelined GEMMs (csrc/ivit_gemm3.h)
+@pytest.mark.parametrize("M,N,K", [(256, 128, 384), (788, 384, 384), (1000, 1152, 384), (513, 1536, 384), (300, 384, 1536),
+                                   (2571, 384, 768), (257, 160, 384), (4099, 256, 1152), (255, 384, 384), (640, 96, 320)])
+def test_planned_linear_epilogues_vs_oracle(H, M, N, K):
+    """ivit_linear_*_planned == oracle linear + requant for the 8-bit, 16-bit and 16-bit + residual epilogues.
+    K % 384 == 0 shapes with M >= 256 run gemm_as_kernel (A-stationary for K = 384, streaming rounds above), others the
+    launch-per-tile kernels behind the same entry points; ragged M / N exercise the scratch-redirected stores."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(M + 3 * N + 7 * K)
+    x = rng.integers(-128, 128, (M, K), dtype=np.int8)
+    w = np.rint(rng.normal(0, 45, (N, K)).clip(-128, 127)).astype(np.int8)
+    b = rng.integers(-2 ** 16, 2 ** 16, N).astype(np.int32)
+    acc = orc.linear_i8(x, w, b)
+    amax = float(np.abs(acc).max())
+    s_pre = (10 ** rng.uniform(-6, -4, N)).astype(np.float32)
+    s_pre[::5] *= 0.5
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    for bits in (8, 16):
+        s_out = np.float32(amax * float(s_pre.mean()) / 2 ** (bits - 1) * 2.0)
+        d = iv.freeze.dyadic(s_pre, s_out)
+        dd = dev(d)
+        plan = H.linear_plan(P(wd), P(bd), P(dd), N, K)
+        out = torch.zeros(M, N, dtype={8: torch.int8, 16: torch.int16}[bits], device="cuda")
+        for rep in range(3):      # repeated launches: a wait-count race shows as a run-to-run difference
+            H.call("ivit_linear_i8_requant_planned", plan.p, P(xd), bits, P(out), M)
+            ref = orc.requant(acc, orc.dyadic(s_pre, s_out), bits)
+            assert np.array_equal(out.cpu().numpy().astype(np.int32), ref), (bits, M, N, K, rep)
+        plan.close()
+    res = rng.integers(-32768, 32768, (M, N)).astype(np.int16)
+    s_t = np.float32(amax * float(s_pre.mean()) / 32768 * 2.0)
+    d_ch = dev(iv.freeze.dyadic(s_pre, s_t))
+    plan = H.linear_plan(P(wd), P(bd), P(d_ch), N, K)
+    t = orc.requant(acc, orc.dyadic(s_pre, s_t), 16)
+    for s_mid, s_res, s_fin in [(3.1e-5, 7.7e-5, 9.1e-5), (1e-4, 3e-4, 2e-4)]:
+        d_main = iv.freeze.dyadic(np.float32(s_mid), np.float32(s_fin))
+        d_res = iv.freeze.dyadic(np.float32(s_res), np.float32(s_fin))
+        out = torch.zeros(M, N, dtype=torch.int16, device="cuda")
+        ref = orc.requant(t, orc.dyadic(np.float32(s_mid), np.float32(s_fin)), 16, res.astype(np.int32),
+                          orc.dyadic(np.float32(s_res), np.float32(s_fin)))
+        for rep in range(3):
+            H.call("ivit_linear_i8_requant_residual_planned", plan.p, P(xd), dyv(d_main), dyv(d_res), P(dev(res)), P(out), M)
+            assert np.array_equal(out.cpu().numpy().astype(np.int32), ref), (M, N, K, s_mid, rep)
+    plan.close()
+
+
+@pytest.mark.parametrize("B,T,Hh,dh", [(8, 197, 6, 64), (3, 197, 6, 64), (2, 577, 12, 64), (5, 50, 4, 96)])
+def test_planned_qkv_scatter_vs_numpy(H, B, T, Hh, dh):
+    """qkv Linear -> QuantAct(8) -> q, k [B,H,T,dh] and v^T [B,H,dh,ldv] through the planned entry point == numpy
+    (register-resident epilogue: half-wave exchange + direct 16-byte stores; v^T byte scatter)."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(B * 31 + T)
+    D = Hh * dh
+    M, ld = B * T, (T + 15) // 16 * 16
+    x = rng.integers(-128, 128, (M, D), dtype=np.int8)
+    w = np.rint(rng.normal(0, 45, (3 * D, D)).clip(-128, 127)).astype(np.int8)
+    b = rng.integers(-2 ** 14, 2 ** 14, 3 * D).astype(np.int32)
+    acc = orc.linear_i8(x, w, b)
+    s_pre = (10 ** rng.uniform(-5.5, -5, 3 * D)).astype(np.float32)
+    s_out = np.float32(float(np.abs(acc).max()) * float(s_pre.mean()) / 128 * 1.5)
+    d = dev(iv.freeze.dyadic(s_pre, s_out))
+    ref = orc.requant(acc, orc.dyadic(s_pre, s_out), 8).reshape(B, T, 3, Hh, dh)
+    wd, bd, xd = dev(w), dev(b), dev(x)
+    plan = H.linear_plan(P(wd), P(bd), P(d), 3 * D, D)
+    q = torch.zeros(B * Hh, T, dh, dtype=torch.int8, device="cuda")
+    k = torch.zeros_like(q)
+    vt = torch.zeros(B * Hh, dh, ld, dtype=torch.int8, device="cuda")
+    H.call("ivit_linear_i8_qkv_planned", plan.p, P(xd), P(q), P(k), P(vt), B, T, Hh, dh, ld)
+    assert np.array_equal(q.cpu().numpy().reshape(B, Hh, T, dh), ref[:, :, 0].transpose(0, 2, 1, 3))
+    assert np.array_equal(k.cpu().numpy().reshape(B, Hh, T, dh), ref[:, :, 1].transpose(0, 2, 1, 3))
+    assert np.array_equal(vt.cpu().numpy().reshape(B, Hh, dh, ld)[..., :T], ref[:, :, 2].transpose(0, 2, 3, 1))
+    assert not vt.cpu().numpy().reshape(B, Hh, dh, ld)[..., T:].any()      # the pad stays untouched
+    plan.close()
+
+
+def test_linear_plan_bounds_and_fallback(H):
+    """the plan proves the pipelined kernel's exactness bounds per channel; a layer outside them (|z*c| may reach 2^31)
+    must be routed to the saturating launch-per-tile kernel and still match the oracle."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(99)
+    M, N, K = 512, 256, 384
+    x = rng.integers(-128, 128, (M, K), dtype=np.int8)
+    w = rng.integers(-128, 128, (N, K), dtype=np.int8)
+    b = rng.integers(-2 ** 10, 2 ** 10, N).astype(np.int32)
+    acc = orc.linear_i8(x, w, b)
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    s_small = np.full(N, 1e-5, np.float32)
+    p_ok = H.linear_plan(P(wd), P(bd), P(dev(iv.freeze.dyadic(s_small, np.float32(1.0)))), N, K)
+    assert p_ok.pipelined_ok and p_ok.single_fma_ok
+    s_big = s_small.copy()
+    s_big[7] = 3.0e4                      # |z*c| up to ~2^37 on one channel
+    d_big = iv.freeze.dyadic(s_big, np.float32(1.0))
+    p_bad = H.linear_plan(P(wd), P(bd), P(dev(d_big)), N, K)
+    assert not p_bad.pipelined_ok
+    out = torch.zeros(M, N, dtype=torch.int8, device="cuda")
+    H.call("ivit_linear_i8_requant_planned", p_bad.p, P(xd), 8, P(out), M)
+    assert np.array_equal(out.cpu().numpy().astype(np.int32), orc.requant(acc, orc.dyadic(s_big, np.float32(1.0)), 8))
+    # a dense +-127 weight row with K = 1536 pushes 128 * sum|w| * m past 2^53: one-FMA form not provable -> two-op form
+    K2 = 1536
+    w2 = np.full((N, K2), 127, np.int8)
+    w2[::2] *= -1
+    x2 = rng.integers(-128, 128, (M, K2), dtype=np.int8)
+    d2 = dev(iv.freeze.dyadic(np.full(N, 1e-6, np.float32), np.float32(0.05)))
+    p2 = H.linear_plan(P(dev(w2)), P(bd), P(d2), N, K2)
+    assert p2.pipelined_ok and not p2.single_fma_ok
+    out2 = torch.zeros(M, N, dtype=torch.int8, device="cuda")
+    H.call("ivit_linear_i8_requant_planned", p2.p, P(dev(x2)), 8, P(out2), M)
+    ref2 = orc.requant(orc.linear_i8(x2, w2, b), orc.dyadic(np.full(N, 1e-6, np.float32), np.float32(0.05)), 8)
+    assert np.array_equal(out2.cpu().numpy().astype(np.int32), ref2)
+    for pl in (p_ok, p_bad, p2):
+        pl.close()
