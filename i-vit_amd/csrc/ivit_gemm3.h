@@ -597,12 +597,26 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
     const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
     const unsigned ring_lds = smem_lds + GA_PANEL, cst_lds = ring_lds + GA_RING;
 
-    // ---- this workgroup's contiguous unit range; unit u = (256-token panel u / tiles_n, 128-channel tile u % tiles_n).
-    // Ranges are handed out so that the workgroups of one XCD (b % 8) hold neighbouring ranges.
+    // ---- this workgroup's units; unit u = (256-token panel u / tiles_n, 128-channel tile u % tiles_n).
+    // K = 384 (A stationary): one CONTIGUOUS range per workgroup (consecutive units share the panel in LDS); ranges are
+    // handed out so that the workgroups of one XCD (b % 8) hold neighbouring ranges.
+    // K > 384 (A streams): the unit space is cut into one contiguous range per XCD and the workgroups of an XCD take
+    // its units ROUND-ROBIN, so that the channel tiles of one panel run at the same time on CUs that share an L2
+    // (a contiguous range per workgroup re-read every panel from beyond the L2: FETCH_SIZE 244 MB vs ~120 MB for fc2).
     const int nwg = gridDim.x, bid = blockIdx.x;
     const long long nunits = (long long)((p.M + 255) >> 8) * p.tiles_n;
-    const int rr = (nwg & 7) == 0 ? (bid & 7) * (nwg >> 3) + (bid >> 3) : bid;
-    const int u_first = (int)(nunits * rr / nwg), u_end = (int)(nunits * (rr + 1) / nwg);
+    int u_first, u_end, u_step;
+    if (p.K == GA_BK * GA_NK) {
+        const int rr = (nwg & 7) == 0 ? (bid & 7) * (nwg >> 3) + (bid >> 3) : bid;
+        u_first = (int)(nunits * rr / nwg);
+        u_end = (int)(nunits * (rr + 1) / nwg);
+        u_step = 1;
+    } else {
+        const int parts = nwg < 8 ? nwg : 8, part = bid % parts;
+        u_step = (nwg - part + parts - 1) / parts;
+        u_first = (int)(nunits * part / parts) + bid / parts;
+        u_end = (int)(nunits * (part + 1) / parts);
+    }
     if (u_first >= u_end) return;
 
     const int8_t *A = reinterpret_cast<const int8_t *>(p.A);
@@ -965,7 +979,7 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
         return t;
     };
     int u_cur = u_first;
-    GaUnit cur = locate(u_cur, 0), prev = cur, next = locate(u_cur + 1, 1);
+    GaUnit cur = locate(u_cur, 0), prev = cur, next = locate(u_cur + u_step, 1);
     // prologue: constants and the slices of pairs 0 and 1 of the first unit
     set_panel(cur.row0);
     set_wtile(cur.col0);
@@ -975,8 +989,8 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
     auto advance = [&]() __attribute__((always_inline)) {
         prev = cur;
         cur = next;
-        ++u_cur;
-        next = locate(u_cur + 1, cur.cb == 2 ? 0 : cur.cb + 1);
+        u_cur += u_step;
+        next = locate(u_cur + u_step, cur.cb == 2 ? 0 : cur.cb + 1);
         return cur.valid != 0;
     };
     v16i acc0[2][2], acc1[2][2];

@@ -357,9 +357,11 @@ int ivit_linear_plan_query(ivit_linear_plan p, int *pipelined_ok, int *single_fm
 }  // extern "C"
 
 // persistent pipelined kernel: shapes it is built for (anything else runs on gemm_glds_kernel / gemm_nt_kernel)
-static inline bool use_gemm3(const ivit_linear_plan_s *pl, const GemmArgs &a) {
-    static const int on = env_int("IVIT_GEMM3", 1);
-    return on && pl->pipelined_ok && (a.K % 64) == 0 && a.K >= 320 && (a.N % 16) == 0 && (a.ldc % 16) == 0 &&
+// IVIT_GEMM3: bit mask of the epilogues that run on the persistent pipelined kernels — 1 requant (8/16-bit), 2 qkv
+// scatter, 4 requant + residual; the others stay on the launch-per-tile kernels (A/B and fallback).
+static inline bool use_gemm3(const ivit_linear_plan_s *pl, const GemmArgs &a, int epi_bit) {
+    static const int on = env_int("IVIT_GEMM3", 7);
+    return (on & epi_bit) && pl->pipelined_ok && (a.K % 64) == 0 && a.K >= 320 && (a.N % 16) == 0 && (a.ldc % 16) == 0 &&
            (a.lda % 16) == 0 && (a.ldb % 16) == 0 && a.M >= 128;
 }
 
@@ -407,7 +409,7 @@ int ivit_linear_i8_requant_planned(ivit_handle h, ivit_linear_plan pl, const int
     REQUIRE(h, bits == 8 || bits == 16, "bits must be 8 or 16");
     GemmArgs a = linear_args(x, pl->w, pl->bias, M, pl->N, pl->K);
     a.out = out; a.dy_ch = pl->dy;
-    if (use_gemm3(pl, a)) return bits == 8 ? launch_gemm3<EPI_RQ8_CH>(h, pl, a) : launch_gemm3<EPI_RQ16_CH>(h, pl, a);
+    if (use_gemm3(pl, a, 1)) return bits == 8 ? launch_gemm3<EPI_RQ8_CH>(h, pl, a) : launch_gemm3<EPI_RQ16_CH>(h, pl, a);
     return ivit_linear_i8_requant(h, x, pl->w, pl->bias, pl->dy, bits, out, M, pl->N, pl->K);
 }
 
@@ -418,7 +420,7 @@ int ivit_linear_i8_requant_residual_planned(ivit_handle h, ivit_linear_plan pl, 
     GemmArgs a = linear_args(x, pl->w, pl->bias, M, pl->N, pl->K);
     a.out = out; a.dy_ch = pl->dy; a.dy_main = dy_main; a.dy_res = dy_res; a.residual = residual;
     const bool res_fast = fabs(dy_main.m * dy_main.r) < RQ_FAST_CLIM && fabs(dy_res.m * dy_res.r) < RQ_FAST_CLIM;
-    if (use_gemm3(pl, a) && res_fast) return launch_gemm3<EPI_RQ16_CH_RES>(h, pl, a);
+    if (use_gemm3(pl, a, 4) && res_fast) return launch_gemm3<EPI_RQ16_CH_RES>(h, pl, a);
     return ivit_linear_i8_requant_residual(h, x, pl->w, pl->bias, pl->dy, dy_main, dy_res, residual, out, M, pl->N, pl->K);
 }
 
@@ -433,7 +435,7 @@ int ivit_linear_i8_qkv_planned(ivit_handle h, ivit_linear_plan pl, const int8_t 
     GemmArgs a = linear_args(x, pl->w, pl->bias, B * T, 3 * D, D);
     a.dy_ch = pl->dy; a.q = q; a.k = k; a.vt = vt;
     a.T = T; a.H = H; a.dh = dh; a.ldv = ldv; a.D = D;
-    if (use_gemm3(pl, a) && (long long)B * T < (1 << 23)) return launch_gemm3<EPI_QKV>(h, pl, a);
+    if (use_gemm3(pl, a, 2) && (long long)B * T < (1 << 23)) return launch_gemm3<EPI_QKV>(h, pl, a);
     return ivit_linear_i8_qkv(h, x, pl->w, pl->bias, pl->dy, q, k, vt, B, T, H, dh, ldv);
 }
 
