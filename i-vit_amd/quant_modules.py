@@ -3,14 +3,22 @@
 behaviour and `forward(x, scale...) -> (y, scale)` shape), running on MI355X through the
 C-ABI of include/ivit.h.
 
-Difference from the reference, by design: activations travel as INTEGER device tensors plus
-an fp32 scale (host tensor), not as fp32 "integer*scale" tensors — the kernels re-derive
-fl(Q*s) where its rounding matters.  A fake-quant fp32 activation
-`X` with scale `s` from reference code converts with `to_int(X, s)`.
+Two tensor conventions, chosen per call by what the caller passes (SURVEY.md §8b "accepting either"):
 
-Only the frozen ("fixed") inference path is implemented on the device (SURVEY.md §8 rows
-a1-a13); calibration (`running_stat=True` statistics) is the host-side next step (§8f N1):
-set `act_scaling_factor` from a calibrated reference checkpoint or `set_scale()`.
+  * INTEGER (native, what the fused engines and this package's own models use): activations are
+    integer device tensors (int8 / int16 / int32; IntLayerNorm's integer-valued fp32 `IntValued`)
+    plus an fp32 scale held on the host — the kernels re-derive fl(Q*s) where its rounding matters
+    (SURVEY.md Appendix A).
+  * FAKE-QUANT fp32 (the reference's own convention, quant_modules.py:204-206): `X = fl(Q*s)` with
+    its scale.  A floating-point activation is converted ONCE per operator with the reference's own
+    `rne(fl(X / s))` (quant_utils.py:220; :94, :359, :426, :484 consume the same quotient), the
+    integer kernel runs, and the result goes back as `fl(Q_out * s_out)` — so reference caller code
+    (e.g. Attention.forward, vit_quant.py:59-88, including its `attn * self.scale`) runs unchanged.
+    A tensor that is not on the integer grid of its scale (a float mask added to logits, say) is
+    refused with a ValueError instead of being rounded silently.
+
+The frozen ("fixed") inference path and the `running_stat=True` calibration branch of QuantAct
+(quant_modules.py:170-192) are implemented.
 There is no CPU fallback: without the HIP library / a GPU every forward raises.
 """
 import ctypes
@@ -66,6 +74,43 @@ def to_int(x_fp32, scale, dtype=torch.int32):
     """integer view of a reference-style fake-quant tensor: rne(x / s) (quant_utils.py:220)"""
     s = torch.as_tensor(_f32(scale), device=x_fp32.device)
     return torch.round(x_fp32 / s).to(dtype)
+
+
+class IntValued(torch.Tensor):
+    """fp32 tensor whose VALUES are integers (IntLayerNorm's output in the integer convention: it can
+    exceed int32).  The subclass is the marker that tells QuantAct not to treat it as fake-quant."""
+
+
+def _is_fake(x):
+    return x.is_floating_point() and not isinstance(x, IntValued)
+
+
+def _scale_t(scale, x, channel_dim=-1):
+    """scale (scalar or per-channel) as an fp32 device tensor broadcastable against x"""
+    sv = _f32(scale)
+    t = torch.as_tensor(sv, device=x.device)
+    if sv.size == 1:
+        return t.reshape(())
+    shape = [1] * x.dim()
+    shape[channel_dim] = sv.size
+    return t.reshape(shape)
+
+
+def from_fake(x, scale, dtype, lo, hi, what, channel_dim=-1):
+    """fake-quant fp32 X = fl(Q*s) -> Q with the reference's rne(fl(X / s)); refuses off-grid or out-of-range input"""
+    q = torch.round(x.float() / _scale_t(scale, x, channel_dim))
+    bad = (q - x.float() / _scale_t(scale, x, channel_dim)).abs().max().item() if x.numel() else 0.0
+    if bad > 0.05:
+        raise ValueError(f"{what}: input is not a fake-quant tensor of the given scale (|x/s - rne(x/s)| up to {bad:.3f}); "
+                         "non-integer products must be folded into the scale or passed separately (e.g. IntSoftmax mask=)")
+    if q.numel() and (q.min().item() < lo or q.max().item() > hi):
+        raise ValueError(f"{what}: rne(x/s) leaves [{lo}, {hi}] — wrong scale or wrong bit width")
+    return q.to(dtype)
+
+
+def to_fake(q, scale, channel_dim=-1):
+    """Q, s -> fl(Q*s) fp32 (quant_modules.py:204-206)"""
+    return q.float().as_subclass(torch.Tensor) * _scale_t(scale, q, channel_dim)
 
 
 class _DyCache:
@@ -137,14 +182,19 @@ class QuantLinear(nn.Linear):
         s_x = _f32(prev_act_scaling_factor)
         if s_x.size != 1:
             raise ValueError("QuantLinear expects a per-tensor input scale")
+        fake = _is_fake(x)
+        if fake:
+            x = from_fake(x, s_x, torch.int8, -128, 127, "QuantLinear")
         if x.dtype != torch.int8:
-            raise TypeError("QuantLinear input must be int8 (use QuantAct first)")
+            raise TypeError("QuantLinear input must be int8 or a fake-quant fp32 tensor (use QuantAct first)")
         c = self._prepare(s_x[0], x.device)
         x2 = x.reshape(-1, self.in_features).contiguous()
         acc = torch.empty(x2.shape[0], self.out_features, dtype=torch.int32, device=x.device)
         handle(x.device).call("ivit_linear_i8", _ptr(x2), _ptr(c["w"]), _ptr(c["b"]) if c["b"] is not None else None,
                               _ptr(acc), x2.shape[0], self.out_features, self.in_features)
-        return acc.reshape(*x.shape[:-1], self.out_features), torch.from_numpy(c["s_b"])
+        acc = acc.reshape(*x.shape[:-1], self.out_features)
+        s_b = torch.from_numpy(c["s_b"])
+        return (to_fake(acc, s_b) if fake else acc), s_b
 
 
 class QuantAct(nn.Module):
@@ -163,6 +213,9 @@ class QuantAct(nn.Module):
         if quant_mode != "symmetric":
             raise ValueError("unknown quant mode: {}".format(quant_mode))
         self._dy = _DyCache()
+        # reference callers expect the input QuantAct (no pre-scale) to hand back fl(q*s) fp32; the integer convention
+        # (default) returns the int8 tensor itself
+        self.fake_quant_input = False
 
     def fix(self):
         self.running_stat = False
@@ -214,8 +267,13 @@ class QuantAct(nn.Module):
         self.set_range(mn, mx)
 
     def forward(self, x, pre_act_scaling_factor=None, identity=None, identity_scaling_factor=None):
+        fake = pre_act_scaling_factor is not None and _is_fake(x)
         if self.running_stat:
-            self._collect_range(x, pre_act_scaling_factor, identity, identity_scaling_factor)
+            if fake or pre_act_scaling_factor is None:
+                # the fp32 activation itself (reference quant_modules.py:167: x_act = x if identity is None else identity + x)
+                self._collect_range(x if identity is None else identity.float() + x.float(), None, None, None)
+            else:
+                self._collect_range(x, pre_act_scaling_factor, identity, identity_scaling_factor)
         s_out = np.float32(self.act_scaling_factor.reshape(-1)[0].item())
         if not s_out > 0:
             raise ValueError("QuantAct has no scale: load act_scaling_factor or call set_scale()")
@@ -230,8 +288,35 @@ class QuantAct(nn.Module):
             xc = x.contiguous().float()
             q = torch.empty(xc.shape, dtype=torch.int8, device=x.device)
             h.call("ivit_quantize_input_f32", _ptr(xc), float(s_out), _ptr(q), xc.numel())
+            if self.fake_quant_input:
+                return to_fake(q, self.act_scaling_factor), self.act_scaling_factor
             return q, self.act_scaling_factor
         s_pre = _f32(pre_act_scaling_factor)
+        # channel dim: last, or dim 1 for the conv layout [B, C, H, W] with a (1, C, 1, 1) scale (quant_modules.py:316-330)
+        ps = tuple(pre_act_scaling_factor.shape) if isinstance(pre_act_scaling_factor, torch.Tensor) else ()
+        conv_layout = len(ps) == 4 and x.dim() == 4 and ps[1] == x.shape[1] and ps[1] > 1
+        cdim = 1 if conv_layout else -1
+        if fake:
+            # the reference's own first step, z = rne(fl(X / s_pre)) in fp32 (quant_utils.py:220): it can exceed int32 after
+            # I-LayerNorm, so it stays an integer-valued fp32 tensor for the fp64 requant kernel
+            x = torch.round(x.float() / _scale_t(s_pre, x, cdim)).as_subclass(IntValued)
+            if identity is not None:
+                identity = from_fake(identity, identity_scaling_factor, torch.int32, -2 ** 31, 2 ** 31 - 1, "QuantAct identity")
+        if conv_layout:
+            x = x.permute(0, 2, 3, 1).contiguous()
+            if x.is_floating_point():
+                x = x.as_subclass(IntValued)
+            if identity is not None:
+                identity = identity.permute(0, 2, 3, 1).contiguous()
+        out = self._requant(x, s_pre, s_out, identity, identity_scaling_factor, bits, out_dt, h)
+        if conv_layout:
+            out = out.permute(0, 3, 1, 2)
+        if fake:
+            return to_fake(out, self.act_scaling_factor), self.act_scaling_factor
+        return out, self.act_scaling_factor
+
+    def _requant(self, x, s_pre, s_out, identity, identity_scaling_factor, bits, out_dt, h):
+        """integer convention: x int32 / int16 / int8 or integer-valued fp32, channel = last dim"""
         C = x.shape[-1]
         if s_pre.size not in (1, C):
             raise NotImplementedError("scale must be per-tensor or per-channel on the last dim")
@@ -249,19 +334,19 @@ class QuantAct(nn.Module):
                 out = torch.empty(x.shape, dtype=out_dt, device=x.device)
                 h.call("ivit_requant_i32_bcast", _ptr(zc), _dyv(d), _ptr(idc), idc.numel(), _dyv(di_host), bits,
                        _ptr(out), zc.numel())
-                return out, self.act_scaling_factor
+                return out
             zi = identity.to(torch.int32).expand(x.shape).contiguous()
         out = torch.empty(x.shape, dtype=out_dt, device=x.device)
         rows = x.numel() // C
         if x.dtype == torch.float32:
-            xc = x.contiguous()
+            xc = x.as_subclass(torch.Tensor).contiguous()
             h.call("ivit_requant_f32", _ptr(xc), _ptr(dd), d.shape[0], _ptr(zi) if zi is not None else None,
                    _ptr(di) if di is not None else None, bits, _ptr(out), rows, C)
         else:
             xc = x.to(torch.int32).contiguous()
             h.call("ivit_requant_i32", _ptr(xc), _ptr(dd), d.shape[0], _ptr(zi) if zi is not None else None,
                    _ptr(di) if di is not None else None, bits, _ptr(out), rows, C)
-        return out, self.act_scaling_factor
+        return out
 
 
 class QuantMatMul(nn.Module):
@@ -281,6 +366,13 @@ class QuantMatMul(nn.Module):
         sA, sB = _f32(pre_act_scaling_factor_A), _f32(pre_act_scaling_factor_B)
         s_out = (sA * sB).astype(np.float32)
         self.act_scaling_factor = torch.from_numpy(s_out)
+        fake = _is_fake(A) or _is_fake(B)
+        if _is_fake(A):      # int8 operand, or the 16-bit Shiftmax output (0 .. 32768)
+            qa = torch.round(A.float() / _scale_t(sA, A))
+            wide = bool(qa.numel() and (qa.max().item() > 127 or qa.min().item() < -128))
+            A = from_fake(A, sA, torch.int32 if wide else torch.int8, 0 if wide else -128, 32768 if wide else 127, "QuantMatMul A")
+        if _is_fake(B):
+            B = from_fake(B, sB, torch.int8, -128, 127, "QuantMatMul B")
         if B.dtype != torch.int8:
             raise TypeError("QuantMatMul: B must be int8")
         M, K = A.shape[-2], A.shape[-1]
@@ -301,7 +393,8 @@ class QuantMatMul(nn.Module):
             Ap = torch.zeros(nb, M, Kp, dtype=torch.int16, device=A.device)   # uint16 payload
             Ap[:, :, :K] = A.reshape(nb, M, K).to(torch.int32).to(torch.int16)
             h.call("ivit_bmm_nt_u16i8", _ptr(Ap), _ptr(Bt), _ptr(C), nb, M, N, K, Kp, Kp, N, M * Kp, N * Kp, M * N)
-        return C.reshape(*batch, M, N), self.act_scaling_factor
+        C = C.reshape(*batch, M, N)
+        return (to_fake(C, self.act_scaling_factor) if fake else C), self.act_scaling_factor
 
 
 class QuantConv2d(nn.Conv2d):
@@ -337,6 +430,9 @@ class QuantConv2d(nn.Conv2d):
                 any(self.padding) or self.groups != 1 or any(d != 1 for d in self.dilation)):
             raise NotImplementedError("QuantConv2d on MI355X: non-overlapping patch convolution only")
         s_x = _f32(pre_act_scaling_factor)[0]
+        fake = _is_fake(x)
+        if fake:
+            x = from_fake(x, s_x, torch.int8, -128, 127, "QuantConv2d")
         key = (np.float32(s_x).tobytes(), str(x.device))
         if self._frozen is None or self._frozen[0] != key:
             w_int, s_w = fz.quantize_weight(self.weight.detach().cpu().numpy())
@@ -355,7 +451,8 @@ class QuantConv2d(nn.Conv2d):
         h.call("ivit_linear_i8", _ptr(rows), _ptr(c["w"]), _ptr(c["b"]), _ptr(acc), rows.shape[0],
                self.out_channels, K)
         y = acc.reshape(B, Hh // P, Ww // P, self.out_channels).permute(0, 3, 1, 2)
-        return y, torch.from_numpy(c["s_b"]).view(1, -1, 1, 1)
+        s_b = torch.from_numpy(c["s_b"]).view(1, -1, 1, 1)
+        return (to_fake(y, s_b, channel_dim=1) if fake else y), s_b
 
 
 class IntLayerNorm(nn.LayerNorm):
@@ -382,6 +479,9 @@ class IntLayerNorm(nn.LayerNorm):
         """x int16 [B, N, C]; returns (z float32 integer-valued [B,N,C], scale[C]) — z is the
         integer the following QuantAct derives (it can exceed int32)."""
         s = _f32(scaling_factor)[0]
+        fake = _is_fake(x)
+        if fake:
+            x = from_fake(x, s, torch.int16, -32768, 32767, "IntLayerNorm")
         if self._frozen is None or self._frozen[0] != str(x.device):
             bi, sc = fz.layernorm_constants(self.weight.detach().cpu().numpy(), self.bias.detach().cpu().numpy())
             self._frozen = (str(x.device), torch.from_numpy(bi).to(x.device), torch.from_numpy(sc).to(x.device), sc)
@@ -397,7 +497,9 @@ class IntLayerNorm(nn.LayerNorm):
         else:
             handle(x.device).call("ivit_layernorm", _ptr(xc), xc.numel() // C, C, float(s), _ptr(bi_d), _ptr(sc_d),
                                   _ptr(z))
-        return z, torch.from_numpy(sc)
+        if fake:
+            return to_fake(z, sc), torch.from_numpy(sc)
+        return z.as_subclass(IntValued), torch.from_numpy(sc)
 
 
 class IntGELU(nn.Module):
@@ -419,13 +521,16 @@ class IntGELU(nn.Module):
 
     def forward(self, x, scaling_factor=None):
         s = np.float32(_f32(scaling_factor)[0])
+        fake = _is_fake(x)
+        if fake:
+            x = from_fake(x, s, torch.int8, -128, 127, "IntGELU")
         C = x.shape[-1]
         xc = x.contiguous()
         out = torch.empty(x.shape, dtype=torch.int16, device=x.device)
         handle(x.device).call("ivit_shiftgelu", _ptr(xc), xc.numel() // C, C, float(s), _ptr(out))
         s_out = np.float32(s * np.float32(1.0 / 2 ** (self.output_bit - 1)))
         self.act_scaling_factor = torch.tensor([float(s_out)])
-        return out, self.act_scaling_factor
+        return (to_fake(out, self.act_scaling_factor) if fake else out), self.act_scaling_factor
 
 
 class IntSoftmax(nn.Module):
@@ -449,6 +554,9 @@ class IntSoftmax(nn.Module):
         """mask: optional float [nW, n, n] (0 / -100.0) — the reference adds it to the fp32 logits
         right before this module (swin_quant.py:151-156); with integer activations it is passed in."""
         s = np.float32(_f32(scaling_factor)[0])
+        fake = _is_fake(x)
+        if fake:
+            x = from_fake(x, s, torch.int8, -128, 127, "IntSoftmax")
         n = x.shape[-1]
         xc = x.contiguous()
         out = torch.empty(x.shape, dtype=torch.int16, device=x.device)    # uint16 payload
@@ -460,4 +568,5 @@ class IntSoftmax(nn.Module):
             handle(x.device).call("ivit_shiftmax", _ptr(xc), xc.numel() // n, n, n, float(s), self.output_bit,
                                   _ptr(out), n)
         self.act_scaling_factor = torch.tensor([1.0 / 2 ** (self.output_bit - 1)])
-        return out.to(torch.int32) & 0xFFFF, self.act_scaling_factor
+        out = out.to(torch.int32) & 0xFFFF
+        return (to_fake(out, self.act_scaling_factor) if fake else out), self.act_scaling_factor

@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from .layers_quant import PatchEmbed, Mlp, DropPath
-from .quant_modules import (QuantLinear, QuantAct, IntLayerNorm, IntSoftmax, IntGELU, QuantMatMul, _f32)
+from .quant_modules import (QuantLinear, QuantAct, IntLayerNorm, IntSoftmax, IntGELU, QuantMatMul, _f32, _is_fake, to_fake)
 from .synth import ViTConfig
 
 __all__ = ["deit_tiny_patch16_224", "deit_small_patch16_224", "deit_base_patch16_224",
@@ -42,7 +42,10 @@ class Attention(nn.Module):
         qkv = x.reshape(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4)
         q, k, v = qkv[0], qkv[1], qkv[2]
         attn, s = self.matmul_1(q, s1, k.transpose(-2, -1), s1)
-        # attn * scale and scale * scale (vit_quant.py:72-73): the integers are unchanged
+        # attn * scale and scale * scale (vit_quant.py:72-73): the integers are unchanged; a fake-quant fp32 `attn`
+        # (reference convention) is scaled exactly like the reference scales it
+        if _is_fake(attn):
+            attn = attn * self.scale
         s = torch.from_numpy((_f32(s) * np.float32(self.scale)).astype(np.float32))
         attn, s = self.qact_attn1(attn, s)
         attn, s = self.int_softmax(attn, s)
@@ -109,6 +112,9 @@ class VisionTransformer(nn.Module):
         self.qact2 = QuantAct()
         self.head = QuantLinear(self.num_features, num_classes) if num_classes > 0 else nn.Identity()
         self.act_out = QuantAct()
+        # False (default): integer tensors between the operators.  True: the reference's fake-quant fp32 tensors
+        # X = fl(Q*s) travel between them (same integers inside every kernel) and forward returns fp32 logits.
+        self.fake_quant = False
 
     # ---- frozen-model plumbing -------------------------------------------------------
     def load_float_weights(self, weights):
@@ -138,7 +144,31 @@ class VisionTransformer(nn.Module):
         return ViTEngine.from_float(self.cfg, w, self.act_scales(), device=device)
 
     # ---- reference forward (vit_quant.py:254-282) ------------------------------------
+    def _forward_features_fake(self, x):
+        """the reference's forward_features (vit_quant.py:254-276) statement by statement, on fake-quant fp32 tensors"""
+        B = x.shape[0]
+        if x.dtype == torch.int8:
+            s = self.qact_input.act_scaling_factor
+            x = to_fake(x, s)
+        else:
+            self.qact_input.fake_quant_input = True
+            x, s = self.qact_input(x)
+        x, s = self.patch_embed(x, s)
+        cls_tokens = self.cls_token.to(x.device).expand(B, -1, -1)     # a float: rounded inside qact1 like in the reference
+        x = torch.cat((cls_tokens, x), dim=1)
+        pos_int = self.qact_pos.quantize_param(self.pos_embed[0]).astype(np.float32)
+        x_pos = to_fake(torch.from_numpy(pos_int).to(x.device).unsqueeze(0), self.qact_pos.act_scaling_factor)
+        x, s = self.qact1(x, s, x_pos, self.qact_pos.act_scaling_factor)
+        for blk in self.blocks:
+            x, s = blk(x, s)
+        x, s = self.norm(x, s)
+        x = x[:, 0]
+        x, s = self.qact2(x.contiguous(), s)
+        return x, s
+
     def forward_features(self, x):
+        if self.fake_quant:
+            return self._forward_features_fake(x)
         B = x.shape[0]
         if x.dtype == torch.int8:      # already-quantised image batch
             s = self.qact_input.act_scaling_factor
