@@ -28,9 +28,11 @@ _DERIVED = ("weight_integer", "bias_integer", "fc_scaling_factor", "conv_scaling
             "relative_position_index", "attn_mask")
 
 
-def _unwrap(obj):
+def _unwrap(obj, trusted=False):
     if isinstance(obj, (str, bytes)) or hasattr(obj, "read"):
-        obj = torch.load(obj, map_location="cpu", weights_only=False)
+        # the reference's checkpoint is a plain state_dict (quant_train.py:261): tensors only.  Full unpickling
+        # (arbitrary code execution) only for a file the caller explicitly vouches for.
+        obj = torch.load(obj, map_location="cpu", weights_only=not trusted)
     for key in ("state_dict", "model", "model_state_dict"):
         if isinstance(obj, dict) and key in obj and isinstance(obj[key], dict):
             obj = obj[key]
@@ -43,9 +45,9 @@ def _unwrap(obj):
     return out
 
 
-def split_state_dict(state_dict):
+def split_state_dict(state_dict, trusted=False):
     """-> (float_params, act_scales, derived): numpy arrays keyed like the reference modules."""
-    sd = _unwrap(state_dict)
+    sd = _unwrap(state_dict, trusted)
     params, scales, derived = {}, {}, {}
     for k, v in sd.items():
         leaf = k.rsplit(".", 1)[-1]
@@ -60,13 +62,13 @@ def split_state_dict(state_dict):
     return params, scales, derived
 
 
-def load_reference_state_dict(model, state_dict, verify=True, freeze=True):
+def load_reference_state_dict(model, state_dict, verify=True, freeze=True, trusted=False):
     """Load a reference state dict into `model` (ivit_amd VisionTransformer / SwinTransformer).
     Returns the list of QuantAct sites that carry no usable scale in the checkpoint (never-called sites
     such as `act_out` / `attn.qact_softmax` hold 0 and are skipped)."""
     from .model_utils import freeze_model
     from .quant_modules import QuantAct, QuantLinear, QuantConv2d
-    params, scales, derived = split_state_dict(state_dict)
+    params, scales, derived = split_state_dict(state_dict, trusted)
     own = dict(model.named_parameters())
     unknown = [k for k in params if k not in own]
     if unknown:

@@ -67,12 +67,14 @@ inline int slice_begin(int batch, int nslices, int i) { return (int)(((long long
 inline int max_slice(int batch, int nslices) { return (batch + nslices - 1) / nslices; }
 
 // one slice on handle `h`
-int run_slice(const ivit_vit_s *m, ivit_handle h, const int8_t *images, int B, char *ws, int32_t *logits) {
+// `Bmax`: images of the LARGEST slice of this forward — every slice uses that slice's buffer layout, so the regions
+// zeroed by ivit_vit_workspace_init are the ones the kernels see whatever the (ragged) slice sizes are
+int run_slice(const ivit_vit_s *m, ivit_handle h, const int8_t *images, int B, int Bmax, char *ws, int32_t *logits) {
     const ivit_vit_config &c = m->cfg;
     const ivit_vit_params &P = m->prm;
     const int T = m->T, D = c.embed_dim, H = c.num_heads, dh = D / H, Hd = c.hidden_dim, ld = m->ld;
     const int M = B * T;
-    const SliceLayout L = slice_layout(m, B);
+    const SliceLayout L = slice_layout(m, Bmax);
     int8_t *patches = (int8_t *)(ws + L.patches), *a8 = (int8_t *)(ws + L.a8), *q = (int8_t *)(ws + L.q),
            *k = (int8_t *)(ws + L.k), *vt = (int8_t *)(ws + L.vt), *ctx8 = (int8_t *)(ws + L.ctx8),
            *h8 = (int8_t *)(ws + L.h8), *g8 = (int8_t *)(ws + L.g8), *cls8 = (int8_t *)(ws + L.cls8);
@@ -239,12 +241,13 @@ int ivit_vit_forward(ivit_vit m, const int8_t *images, int batch, int nslices, v
     REQUIRE(h, ((uintptr_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
     const size_t img_bytes = (size_t)m->cfg.in_chans * m->cfg.img_size * m->cfg.img_size;
     const size_t stride = slice_layout(m, max_slice(batch, nslices)).total;
-    if (nslices == 1) return run_slice(m, h, images, batch, (char *)workspace, logits);
+    if (nslices == 1) return run_slice(m, h, images, batch, batch, (char *)workspace, logits);
     if (hipEventRecord(m->fork, h->stream) != hipSuccess) return IVIT_ERR_HIP;
     for (int i = 0; i < nslices; ++i) {
         const int b0 = slice_begin(batch, nslices, i), b1 = slice_begin(batch, nslices, i + 1);
         if (hipStreamWaitEvent(m->streams[i], m->fork, 0) != hipSuccess) return IVIT_ERR_HIP;
-        rc = run_slice(m, m->slice_h[i], images + (size_t)b0 * img_bytes, b1 - b0, (char *)workspace + stride * (size_t)i,
+        rc = run_slice(m, m->slice_h[i], images + (size_t)b0 * img_bytes, b1 - b0, max_slice(batch, nslices),
+                       (char *)workspace + stride * (size_t)i,
                        logits + (size_t)b0 * m->cfg.num_classes);
         if (rc != IVIT_OK) return rc;
         if (hipEventRecord(m->done[i], m->streams[i]) != hipSuccess) return IVIT_ERR_HIP;

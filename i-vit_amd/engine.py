@@ -144,6 +144,8 @@ class ViTEngine:
 
     def _native_buffers(self, B, nslices):
         key = (B, nslices)
+        if key not in self._native_ws and len(self._native_ws) >= 4:
+            self._native_ws.pop(next(iter(self._native_ws)))          # bounded: at most 4 (batch, slices) shapes resident
         if key not in self._native_ws:
             n = ctypes.c_size_t()
             self.h._check(self.h.lib.ivit_vit_workspace_bytes(self.model, B, nslices, ctypes.byref(n)), "ivit_vit_workspace_bytes")
@@ -153,11 +155,15 @@ class ViTEngine:
             self._native_ws[key] = (ws, logits)
         return self._native_ws[key]
 
-    def forward(self, images, nslices=1):
+    def forward(self, images, nslices=1, copy=False):
         """images: int8 device tensor [B, C, H, W] (already quantised, scale s_in) -> int32 logits
         [B, num_classes] (head accumulators).  One native call; nslices > 1 cuts the batch into slices
         on the runner's internal HIP streams (VALU-bound kernels of one slice share the chip with the
-        MFMA-bound GEMMs of another).  Same integers for every nslices."""
+        MFMA-bound GEMMs of another).  Same integers for every nslices.
+
+        The returned tensor is the engine's OWN output buffer for this (batch, nslices): the next forward /
+        graph replay of the same shape overwrites it (nothing is allocated per call).  Pass copy=True — or
+        clone it — when results of several batches are kept (an eval loop collecting logits)."""
         assert images.dtype == torch.int8 and images.is_contiguous() and images.device == self.device
         self.h.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
         B = images.shape[0]
@@ -165,7 +171,7 @@ class ViTEngine:
         ws, logits = self._native_buffers(B, nslices)
         self.h._check(self.h.lib.ivit_vit_forward(self.model, _P(images.data_ptr()), B, nslices, _P(ws.data_ptr()),
                                                   ws.numel(), _P(logits.data_ptr())), "ivit_vit_forward")
-        return logits
+        return logits.clone() if copy else logits
 
     def forward_streams(self, images, nstreams=2):
         return self.forward(images, nslices=nstreams)

@@ -157,7 +157,10 @@ class QuantLinear(nn.Linear):
         pass
 
     def _prepare(self, s_x, device):
-        key = (np.float32(s_x).tobytes(), str(device))
+        # the frozen integers depend on the float parameters: their in-place version counters are part of the key, so
+        # load_state_dict / copy_ after a forward re-quantises instead of silently keeping the old int8 weights
+        key = (np.float32(s_x).tobytes(), str(device), self.weight._version, id(self.weight),
+               None if self.bias is None else (self.bias._version, id(self.bias)))
         if self._frozen is not None and self._frozen[0] == key:
             return self._frozen[1]
         if not self.per_channel:
@@ -433,7 +436,7 @@ class QuantConv2d(nn.Conv2d):
         fake = _is_fake(x)
         if fake:
             x = from_fake(x, s_x, torch.int8, -128, 127, "QuantConv2d")
-        key = (np.float32(s_x).tobytes(), str(x.device))
+        key = (np.float32(s_x).tobytes(), str(x.device), self.weight._version, id(self.weight), self.bias._version, id(self.bias))
         if self._frozen is None or self._frozen[0] != key:
             w_int, s_w = fz.quantize_weight(self.weight.detach().cpu().numpy())
             b_int, s_b = fz.quantize_bias(self.bias.detach().cpu().numpy(), s_w, s_x)
@@ -482,9 +485,10 @@ class IntLayerNorm(nn.LayerNorm):
         fake = _is_fake(x)
         if fake:
             x = from_fake(x, s, torch.int16, -32768, 32767, "IntLayerNorm")
-        if self._frozen is None or self._frozen[0] != str(x.device):
+        key = (str(x.device), self.weight._version, id(self.weight), self.bias._version, id(self.bias))
+        if self._frozen is None or self._frozen[0] != key:
             bi, sc = fz.layernorm_constants(self.weight.detach().cpu().numpy(), self.bias.detach().cpu().numpy())
-            self._frozen = (str(x.device), torch.from_numpy(bi).to(x.device), torch.from_numpy(sc).to(x.device), sc)
+            self._frozen = (key, torch.from_numpy(bi).to(x.device), torch.from_numpy(sc).to(x.device), sc)
             self.bias_integer = torch.from_numpy(bi)
             self.norm_scaling_factor = torch.from_numpy(sc)
         _, bi_d, sc_d, sc = self._frozen

@@ -152,7 +152,7 @@ class SwinEngine:
         self.f = {k: v[1] for k, v in host.items() if v[0] == "f"}
         self.dy = {k: _lib.Dyadic(v[1], v[2]) for k, v in host.items() if v[0] == "dy"}
         self.t = _BlobView(self.blob, table)
-        self.h = _lib.Handle(self.device.index or 0, torch.cuda.current_stream(self.device).cuda_stream)
+        self.h = _lib.Handle(self.device.index if self.device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(self.device).cuda_stream)
         self._build_native()
         # per-layer ShiftGELU(+requant) tables for forward_ops (the native runner owns its own copies)
         cfg = self.cfg

@@ -926,3 +926,54 @@ def test_fake_quant_rejects_off_grid_tensors(H):
     lin = iv.QuantLinear(64, 32)
     with pytest.raises(ValueError):
         lin(torch.full((4, 64), 1000.0, device="cuda"), np.float32(1.0))       # outside int8 for this scale
+
+
+def test_reloaded_weights_requantise(H):
+    """the frozen-integer cache of QuantLinear / IntLayerNorm follows the float parameters — loading new
+    weights into a model that has already run must change the integers it computes with."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(3)
+    lin = iv.QuantLinear(64, 32).cuda()
+    x = dev(rng.integers(-128, 128, (8, 64), dtype=np.int8))
+    outs = []
+    for seed in (1, 2):
+        w = np.random.default_rng(seed).normal(0, 0.05, (32, 64)).astype(np.float32)
+        b = np.random.default_rng(seed + 10).normal(0, 0.1, 32).astype(np.float32)
+        lin.load_state_dict({"weight": torch.from_numpy(w), "bias": torch.from_numpy(b)}, strict=False)
+        acc, s = lin(x, np.float32(0.02))
+        w_int, s_w = iv.freeze.quantize_weight(w)
+        b_int, _ = iv.freeze.quantize_bias(b, s_w, np.float32(0.02))
+        assert np.array_equal(acc.cpu().numpy(), orc.linear_i8(x.cpu().numpy(), w_int, b_int)), seed
+        outs.append(acc.cpu().numpy())
+    assert not np.array_equal(outs[0], outs[1])
+    ln = iv.IntLayerNorm(64).cuda()
+    xi = dev(rng.integers(-3000, 3000, (2, 5, 64)).astype(np.int16))
+    z1, _ = ln(xi, np.float32(0.01))
+    with torch.no_grad():
+        ln.weight.copy_(torch.linspace(0.5, 2.0, 64))
+    z2, _ = ln(xi, np.float32(0.01))
+    assert not torch.equal(z1, z2)
+
+
+def test_ragged_slices_head_dim_32():
+    """uneven slices (5 images over 3 streams) on the unfused-attention path (head dim 32) — every slice
+    runs on the largest slice's buffer layout, whose pads ivit_vit_workspace_init zeroed."""
+    from oracle import oracle as orc
+    cfg = iv.ViTConfig("ragged32", img_size=24, patch_size=8, num_classes=7, embed_dim=64, depth=2, num_heads=2)
+    assert cfg.head_dim == 32
+    w = iv.make_vit_weights(cfg, seed=5)
+    m = iv.VisionTransformer(img_size=24, patch_size=8, num_classes=7, embed_dim=64, depth=2, num_heads=2, mlp_ratio=4)
+    m.load_float_weights(w)
+    with torch.no_grad():
+        m(dev(iv.make_calibration_batch(cfg, 3, seed=17)))
+    iv.freeze_model(m)
+    sc = {k: v for k, v in m.act_scales().items() if v > 0}
+    eng = m.compile()
+    imgs = iv.make_images_int8(cfg, 5, seed=23)
+    ref, _ = orc.OracleViT(cfg, w, sc).forward(imgs)
+    for ns in (3, 2, 1):
+        got = eng.forward(dev(imgs), nslices=ns, copy=True).cpu().numpy()
+        assert np.array_equal(got, ref), ns
+    a = eng.forward(dev(imgs), nslices=1, copy=True)
+    b = eng.forward(dev(iv.make_images_int8(cfg, 5, seed=24)), nslices=1)
+    assert not torch.equal(a, b)          # copy=True: `a` survived the second forward
