@@ -151,6 +151,8 @@ SIGNATURES = {
     "ivit_linear_i8_requant": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I],
     "ivit_linear_i8_requant_residual": [_P, _P, _P, _P, _P, Dyadic, Dyadic, _P, _P, _I, _I, _I],
     "ivit_linear_i8_qkv": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I],
+    "ivit_constants_upload": [_P, _P, ctypes.c_size_t, _P],
+    "ivit_constants_broadcast": [_P, _P, ctypes.c_size_t, _I, _P],
     "ivit_linear_plan_create": [_P, _P, _P, _P, _I, _I, ctypes.POINTER(_P)],
     "ivit_linear_i8_requant_planned": [_P, _P, _P, _I, _P, _I],
     "ivit_linear_i8_requant_residual_planned": [_P, _P, _P, Dyadic, Dyadic, _P, _P, _I],

@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <new>
+#include <dlfcn.h>
 #include "ivit_device.h"
 #include "ivit_elementwise.h"
 #include "ivit_gemm.h"
@@ -260,6 +261,40 @@ int ivit_attn_pv_requant(ivit_handle h, const uint16_t *p, const int8_t *vt, ivi
 
 }  // extern "C"
 
+
+
+// ---------------------------------------------------------------- constants: upload / RCCL broadcast
+extern "C" {
+
+int ivit_constants_upload(ivit_handle h, const void *host_blob, size_t bytes, void *device_blob) {
+    CHECK_H(h);
+    REQUIRE(h, host_blob && device_blob && bytes > 0, "bad arguments");
+    hipError_t e = hipMemcpyAsync(device_blob, host_blob, bytes, hipMemcpyHostToDevice, h->stream);
+    if (e != hipSuccess) { snprintf(h->err, sizeof(h->err), "ivit_constants_upload: %s", hipGetErrorString(e)); return IVIT_ERR_HIP; }
+    return IVIT_OK;
+}
+
+// ncclBroadcast(sendbuff, recvbuff, count, datatype, root, comm, stream) resolved from librccl.so at first use, so that
+// libivit_hip.so itself carries no link-time dependency on RCCL (single-GPU users never load it)
+int ivit_constants_broadcast(ivit_handle h, void *device_blob, size_t bytes, int root, void *rccl_comm) {
+    CHECK_H(h);
+    REQUIRE(h, device_blob && rccl_comm && bytes > 0 && root >= 0, "bad arguments");
+    typedef int (*bcast_fn)(const void *, void *, size_t, int, int, void *, hipStream_t);
+    static bcast_fn fn = nullptr;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        void *lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (lib) fn = (bcast_fn)dlsym(lib, "ncclBroadcast");
+    }
+    if (!fn) { snprintf(h->err, sizeof(h->err), "ivit_constants_broadcast: librccl.so / ncclBroadcast not found"); return IVIT_ERR_UNSUPPORTED; }
+    const int rc = fn(device_blob, device_blob, bytes, /* ncclUint8 */ 1, root, rccl_comm, h->stream);   // in place: one ring over xGMI
+    if (rc != 0) { snprintf(h->err, sizeof(h->err), "ivit_constants_broadcast: ncclBroadcast returned %d", rc); return IVIT_ERR_HIP; }
+    return IVIT_OK;
+}
+
+}  // extern "C"
 
 // ---------------------------------------------------------------- linear plans (frozen QuantLinear)
 // One wavefront per output channel: c[n] = m*2^-e, zmax[n] = 128 * sum_k |W[n,k]| + |bias[n]| >= |acc + bias|.

@@ -92,6 +92,17 @@ int ivit_linear_i8_qkv(ivit_handle h, const int8_t *x, const int8_t *w, const in
                        const ivit_dyadic *dy_ch, int8_t *q, int8_t *k, int8_t *vt, int B, int T,
                        int H, int dh, int ldv);
 
+/* ---- constants: one packed byte blob per frozen model (int8 weights, int32 biases, dyadic tables, position
+ * embedding; layout = the host packer's table) — how a C host distributes them without
+ * Python or torch.distributed (SURVEY.md §8b minimum surface, §8e).  Replaces the reference's per-GPU
+ * `model.cuda()` of fp32 parameters + per-forward re-quantisation (quant_modules.py:68-91).
+ * upload: host -> device on the handle's stream (asynchronous; the host buffer must stay valid until the stream
+ * reaches it).  broadcast: in-place ncclBroadcast of the device blob from rank `root` over a caller-supplied RCCL
+ * communicator (ncclComm_t), enqueued on the handle's stream — ONE large message, ring over xGMI; the only
+ * collective of the data-parallel path.  librccl.so is resolved at first use.                                   */
+int ivit_constants_upload(ivit_handle h, const void *host_blob, size_t bytes, void *device_blob);
+int ivit_constants_broadcast(ivit_handle h, void *device_blob, size_t bytes, int root, void *rccl_comm);
+
 /* ---- linear plans: a frozen QuantLinear prepared once (quant_modules.py:67-97 with QuantAct.fix(), :153-157).
  * ivit_linear_plan_create precomputes the per-channel multipliers c[n] = m*2^-e and checks, from
  * sum_k |w[n,k]| and bias[n], the two bounds under which the persistent pipelined GEMM (csrc/ivit_gemm3.h)

@@ -977,3 +977,34 @@ def test_ragged_slices_head_dim_32():
     a = eng.forward(dev(imgs), nslices=1, copy=True)
     b = eng.forward(dev(iv.make_images_int8(cfg, 5, seed=24)), nslices=1)
     assert not torch.equal(a, b)          # copy=True: `a` survived the second forward
+
+
+def test_constants_upload_and_rccl_broadcast(H):
+    """the C-ABI path a C host uses to distribute the packed integer constants: ivit_constants_upload (host -> device)
+    and ivit_constants_broadcast (ncclBroadcast over a caller-supplied RCCL communicator).  One GPU here: a 1-rank
+    communicator made with librccl directly (ncclGetUniqueId + ncclCommInitRank) — the broadcast must leave rank 0's
+    bytes intact and the uploaded blob must drive the native runner to the golden logits."""
+    import ctypes
+    from ivit_amd.engine import ViTEngine, pack_constants
+    g = load_golden("micro_vit_b2.npz")
+    cfg = iv.CONFIGS[str(g["cfg_name"])]
+    consts, f32 = iv.freeze.freeze_vit(cfg, iv.make_vit_weights(cfg, int(g["seed"])), golden_scales(g))
+    blob, table = pack_constants(consts)
+    dblob = torch.zeros(blob.size, dtype=torch.uint8, device="cuda")
+    H.call("ivit_constants_upload", blob.ctypes.data_as(_P), blob.size, P(dblob))
+    rccl = ctypes.CDLL("librccl.so")
+
+    class UID(ctypes.Structure):
+        _fields_ = [("b", ctypes.c_char * 128)]
+    uid, comm = UID(), ctypes.c_void_p()
+    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UID, ctypes.c_int]
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+    H.call("ivit_constants_broadcast", P(dblob), blob.size, 0, comm)
+    torch.cuda.synchronize()
+    assert np.array_equal(dblob.cpu().numpy(), blob)
+    rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+    rccl.ncclCommDestroy(comm)
+    eng = ViTEngine(cfg, None, f32, blob=dblob, table=table)
+    imgs = iv.make_images_int8(cfg, int(g["batch"]), int(g["images_seed"]))
+    assert np.array_equal(eng.forward(dev(imgs)).cpu().numpy(), g["logits_int"])
