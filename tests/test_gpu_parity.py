@@ -1008,3 +1008,109 @@ def test_constants_upload_and_rccl_broadcast(H):
     eng = ViTEngine(cfg, None, f32, blob=dblob, table=table)
     imgs = iv.make_images_int8(cfg, int(g["batch"]), int(g["images_seed"]))
     assert np.array_equal(eng.forward(dev(imgs)).cpu().numpy(), g["logits_int"])
+
+
+# ---------------------------------------------------------------- full-size configs, model zoo, Swin checkpoints
+@pytest.mark.parametrize("fname,B", [("deit_base_b2.npz", 64), ("vit_base_384_b1.npz", 128)])
+def test_full_size_batch_properties_vit_configs(fname, B):
+    """BASELINE configs 3 and 5 at the per-GPU batch they name (DeiT-B 512 / 8 = 64, ViT-B@384 1024 / 8 = 128): large-M
+    code paths (grid caps, 64-bit offsets, XCD maps, the pipelined GEMMs' multi-round K = 768 / 3072) under the same
+    size-independent properties as DeiT-S — golden prefix, permutation equivariance, duplicates, slices, hipGraph."""
+    g = load_golden(fname)
+    cfg, w, eng = _engine_for(g)
+    gb = int(g["batch"])
+    imgs = np.concatenate([iv.make_images_int8(cfg, gb, int(g["images_seed"])), iv.make_images_int8(cfg, B - gb, seed=11)])
+    imgs[B - gb:] = imgs[:gb]                                   # duplicates at the far end of the batch
+    d = dev(imgs)
+    ref = eng.forward(d, copy=True).cpu().numpy()
+    assert np.array_equal(ref[:gb], g["logits_int"])
+    assert np.array_equal(ref[B - gb:], ref[:gb])
+    perm = np.random.default_rng(5).permutation(B)
+    assert np.array_equal(eng.forward(dev(imgs[perm])).cpu().numpy(), ref[perm])
+    assert np.array_equal(eng.forward(d, nslices=2).cpu().numpy(), ref)
+    rep = eng.capture(d, 2)
+    out = rep()
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), ref)
+
+
+def test_full_size_batch_properties_swin_tiny_b256():
+    """BASELINE config 4 at full size (Swin-T, 256 images) through the native Swin runner."""
+    from ivit_amd.swin_engine import SwinEngine
+    g = load_golden("swin_tiny_b1.npz")
+    cfg = iv.SWIN_CONFIGS[str(g["cfg_name"])]
+    eng = SwinEngine(cfg, iv.make_swin_weights(cfg, int(g["seed"])), golden_scales(g))
+    B = 256
+    imgs = np.concatenate([iv.make_images_int8(cfg, 1, int(g["images_seed"])), iv.make_images_int8(cfg, B - 1, seed=11)])
+    imgs[255] = imgs[0]
+    d = dev(imgs)
+    ref = eng.forward(d).clone().cpu().numpy()
+    assert np.array_equal(ref[:1], g["logits_int"])
+    assert np.array_equal(ref[255], ref[0])
+    perm = np.random.default_rng(7).permutation(B)
+    assert np.array_equal(eng.forward(dev(imgs[perm])).cpu().numpy(), ref[perm])
+    assert np.array_equal(eng.forward(d, nslices=4).cpu().numpy(), ref)
+    rep = eng.capture(d, 4)
+    out = rep()
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), ref)
+
+
+def test_model_zoo_vit_large_golden():
+    """vit_large_patch16_224 (D = 1024, 24 blocks, 16 heads; vit_quant.py:365-381) through the native
+    runner and the per-operator path == the reference's int32 logits."""
+    g = load_golden("vit_large_b1.npz")
+    cfg, w, eng = _engine_for(g)
+    imgs = dev(iv.make_images_int8(cfg, int(g["batch"]), int(g["images_seed"])))
+    assert np.array_equal(eng.forward(imgs).cpu().numpy(), g["logits_int"])
+    assert np.array_equal(eng.forward_ops(imgs).cpu().numpy(), g["logits_int"])
+    m = iv.vit_large_patch16_224()
+    assert (m.cfg.embed_dim, m.cfg.depth, m.cfg.num_heads) == (cfg.embed_dim, cfg.depth, cfg.num_heads)
+
+
+def test_model_zoo_swin_small_golden():
+    """swin_small_patch4_window7_224 (depths 2/2/18/2; swin_quant.py:588-606): the fused SwinEngine
+    (C = 96 stage-0 fused Mlp, window attention) and the reference-shaped operator chain == the reference's logits."""
+    from ivit_amd.swin_engine import SwinEngine
+    from ivit_amd.swin_quant import SwinTransformer
+    g = load_golden("swin_small_b1.npz")
+    cfg = iv.SWIN_CONFIGS[str(g["cfg_name"])]
+    w = iv.make_swin_weights(cfg, int(g["seed"]))
+    imgs = iv.make_images_int8(cfg, int(g["batch"]), int(g["images_seed"]))
+    eng = SwinEngine(cfg, w, golden_scales(g))
+    assert np.array_equal(eng.forward(dev(imgs)).cpu().numpy(), g["logits_int"])
+    assert np.array_equal(eng.forward(dev(np.concatenate([imgs, imgs, imgs])), nslices=3).cpu().numpy(),
+                          np.concatenate([g["logits_int"]] * 3))
+    m = SwinTransformer(img_size=cfg.img_size, patch_size=cfg.patch_size, num_classes=cfg.num_classes,
+                        embed_dim=cfg.embed_dim, depths=cfg.depths, num_heads=cfg.num_heads,
+                        window_size=cfg.window_size, mlp_ratio=cfg.mlp_ratio)
+    m.load_float_weights(w).load_act_scales(golden_scales(g))
+    iv.freeze_model(m)
+    with torch.no_grad():
+        acc, _ = m(dev(imgs))
+    assert np.array_equal(acc.cpu().numpy(), g["logits_int"])
+
+
+def test_imported_reference_swin_state_dict_runs_to_golden_logits():
+    """checkpoint importer on a SWIN state dict (the reference's own post-forward `state_dict()`, buffers stored as a
+    fixture): -> operator chain and fused SwinEngine -> the reference's logits."""
+    from ivit_amd import checkpoint as ck
+    from ivit_amd.swin_quant import SwinTransformer
+    from ivit_amd.swin_engine import SwinEngine
+    f = load_golden("micro_swin_state_dict.npz")
+    g = load_golden("micro_swin_b2.npz")
+    cfg = iv.SWIN_CONFIGS[str(f["cfg_name"])]
+    w = iv.make_swin_weights(cfg, int(f["seed"]))
+    sd = {str(k): torch.from_numpy(np.asarray(w[str(k)] if str(k) in w else f["buf/" + str(k)]).copy()) for k in f["keys"]}
+    m = SwinTransformer(img_size=cfg.img_size, patch_size=cfg.patch_size, num_classes=cfg.num_classes,
+                        embed_dim=cfg.embed_dim, depths=cfg.depths, num_heads=cfg.num_heads,
+                        window_size=cfg.window_size, mlp_ratio=cfg.mlp_ratio)
+    ck.load_reference_state_dict(m, {"state_dict": sd})
+    imgs = iv.make_images_int8(cfg, int(g["batch"]), int(g["images_seed"]))
+    with torch.no_grad():
+        acc, _ = m(dev(imgs))
+    assert np.array_equal(acc.cpu().numpy(), g["logits_int"])
+    scales = {n: np.float32(mod.act_scaling_factor.reshape(-1)[0].item()) for n, mod in m.named_modules()
+              if type(mod) is iv.QuantAct and float(mod.act_scaling_factor.reshape(-1)[0]) > 0}
+    eng = SwinEngine(cfg, w, scales)
+    assert np.array_equal(eng.forward(dev(imgs)).cpu().numpy(), g["logits_int"])

@@ -283,6 +283,11 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     models = rh.load_reference()
     torch.manual_seed(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "--large":
+        # the larger members of the model zoo: ViT-L and Swin-S, one image each
+        model_fixture(models, "vit_large", 1, 1, 0, False, "vit_large_b1.npz")
+        swin_fixture(models, "swin_small", 1, 1, 0, False, "swin_small_b1.npz")
+        return
     op_fixtures(models)
     model_fixture(models, "micro_vit", 2, 4, 0, True, "micro_vit_b2.npz")
     model_fixture(models, "micro_vit2h", 3, 4, 0, True, "micro_vit2h_b3.npz")
