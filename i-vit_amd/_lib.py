@@ -127,6 +127,7 @@ SIGNATURES = {
     "ivit_set_stream": [_P, _P],
     "ivit_quantize_input_f32": [_P, _P, _F, _P, _L],
     "ivit_normalize_quantize_u8": [_P, _P, _I, _I, _I, ctypes.POINTER(_F), ctypes.POINTER(_F), _F, _P],
+    "ivit_resize_center_crop_u8": [_P, _P, _I, _I, _I, _I, _I, _P, _P],
     "ivit_requant_i16": [_P, _P, _P, _I, _P, _P, _I, _P, _L, _I],
     "ivit_layernorm_tokenorder_requant": [_P, _P, _L, _I, _F, _P, _P, _P, _I, _P],
     "ivit_patch_norm_tokenorder": [_P, _P, _L, _I, _F, _P, _P, _P, Dyadic, _I, _P],

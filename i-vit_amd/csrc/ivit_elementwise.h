@@ -68,6 +68,86 @@ __global__ __launch_bounds__(256) void normalize_quantize_u8_kernel(const unsign
 }
 
 // ---------------------------------------------------------------------------
+// N3: Resize(size, bicubic) + CenterCrop(crop) of the reference's eval transform (utils/data_utils.py:82-88) on
+// the device, uint8 HWC in / uint8 HWC out.  The reference resizes with PIL (absent from this image: no pin
+// possible); the algorithm restated here is the antialiased separable bicubic (a = -0.5, support scaled by the
+// down-scale factor, weights normalised per output pixel) as torch's F.interpolate(mode="bicubic", antialias=True)
+// defines it, in fp32 with this fixed operation order (oracle/oracle.py::resize_center_crop_u8 restates it line by
+// line; tests/golden/resize.npz pins the oracle against torch within 1 LSB on < 1e-3 of the pixels).
+// Two passes: horizontal into an fp32 workspace (only the cropped columns), then vertical + rne + clamp.
+__device__ __forceinline__ float cubic_aa(float x) {
+    const float a = -0.5f;
+    x = fabsf(x);
+    if (x < 1.0f) return ((a + 2.0f) * x - (a + 3.0f)) * x * x + 1.0f;
+    if (x < 2.0f) return (((a * x) - (5.0f * a)) * x + (8.0f * a)) * x - (4.0f * a);
+    return 0.0f;
+}
+// taps of output index i along one axis: first input index and count; the weights are re-evaluated by `tap_w`
+struct AaTaps { int xmin, xsize; float center, invscale, total; };
+__device__ __forceinline__ AaTaps aa_taps(int i, int in_size, int out_size) {
+    AaTaps t;
+    const float scale = (float)in_size / (float)out_size;
+    const float support = scale >= 1.0f ? 2.0f * scale : 2.0f;
+    t.invscale = scale >= 1.0f ? 1.0f / scale : 1.0f;
+    t.center = scale * ((float)i + 0.5f);
+    t.xmin = max((int)(t.center - support + 0.5f), 0);
+    t.xsize = min((int)(t.center + support + 0.5f), in_size) - t.xmin;
+    float tot = 0.0f;
+    for (int j = 0; j < t.xsize; ++j) tot += cubic_aa(((float)(j + t.xmin) - t.center + 0.5f) * t.invscale);
+    t.total = tot;
+    return t;
+}
+__device__ __forceinline__ float tap_w(const AaTaps &t, int j) {
+    return cubic_aa(((float)(j + t.xmin) - t.center + 0.5f) * t.invscale) / t.total;
+}
+// pass 1: tmp[b, y, xo, c] = sum_j w_j * in[b, y, xmin + j, c] for the cropped output columns xo
+__global__ __launch_bounds__(256) void resize_h_kernel(const unsigned char *__restrict__ in, int B, int H0, int W0, int Wr,
+                                                       int left, int crop, float *__restrict__ tmp) {
+    const long long total = (long long)B * H0 * crop;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int xo = (int)(i % crop);
+        const long long by = i / crop;                       // b * H0 + y
+        const AaTaps t = aa_taps(xo + left, W0, Wr);
+        const unsigned char *row = in + (by * W0 + t.xmin) * 3;
+        float w = tap_w(t, 0);
+        float a0 = (float)row[0] * w, a1 = (float)row[1] * w, a2 = (float)row[2] * w;
+        for (int j = 1; j < t.xsize; ++j) {
+            w = tap_w(t, j);
+            a0 += (float)row[j * 3] * w;
+            a1 += (float)row[j * 3 + 1] * w;
+            a2 += (float)row[j * 3 + 2] * w;
+        }
+        float *o = tmp + i * 3;
+        o[0] = a0; o[1] = a1; o[2] = a2;
+    }
+}
+// pass 2: out[b, yo, xo, c] = clamp(rne(sum_j w_j * tmp[b, ymin + j, xo, c]), 0, 255) for the cropped rows yo
+__global__ __launch_bounds__(256) void resize_v_kernel(const float *__restrict__ tmp, int B, int H0, int Hr, int top, int crop,
+                                                       unsigned char *__restrict__ out) {
+    const long long total = (long long)B * crop * crop;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int xo = (int)(i % crop);
+        const int yo = (int)((i / crop) % crop);
+        const long long b = i / ((long long)crop * crop);
+        const AaTaps t = aa_taps(yo + top, H0, Hr);
+        const float *col = tmp + ((b * H0 + t.xmin) * crop + xo) * 3;
+        const long long rs = (long long)crop * 3;
+        float w = tap_w(t, 0);
+        float a0 = col[0] * w, a1 = col[1] * w, a2 = col[2] * w;
+        for (int j = 1; j < t.xsize; ++j) {
+            w = tap_w(t, j);
+            a0 += col[j * rs] * w;
+            a1 += col[j * rs + 1] * w;
+            a2 += col[j * rs + 2] * w;
+        }
+        unsigned char *o = out + i * 3;
+        o[0] = (unsigned char)(int)fminf(fmaxf(rintf(a0), 0.f), 255.f);
+        o[1] = (unsigned char)(int)fminf(fmaxf(rintf(a1), 0.f), 255.f);
+        o[2] = (unsigned char)(int)fminf(fmaxf(rintf(a2), 0.f), 255.f);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // a3: generic dyadic requant (quant_utils.py:213-253); one thread per element group
 template <typename ZT, int BITS>
 __global__ __launch_bounds__(256) void requant_kernel(const ZT *__restrict__ z, const ivit_dyadic *__restrict__ dy,

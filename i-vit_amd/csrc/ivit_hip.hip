@@ -95,6 +95,23 @@ int ivit_quantize_input_f32(ivit_handle h, const float *x, float scale, int8_t *
     return IVIT_OK;
 }
 
+int ivit_resize_center_crop_u8(ivit_handle h, const uint8_t *hwc, int B, int H0, int W0, int size, int crop,
+                               float *workspace, uint8_t *out_hwc) {
+    CHECK_H(h);
+    REQUIRE(h, hwc && workspace && out_hwc && B > 0 && H0 > 0 && W0 > 0 && size > 0 && crop > 0, "bad arguments");
+    // torchvision Resize(int): the SHORTER side becomes `size`, the longer int(size * long / short); CenterCrop offsets
+    // int(round((dim - crop) / 2.0))
+    int Hr, Wr;
+    if (H0 <= W0) { Hr = size; Wr = (int)((long long)size * W0 / H0); }
+    else { Wr = size; Hr = (int)((long long)size * H0 / W0); }
+    REQUIRE(h, crop <= Hr && crop <= Wr, "crop larger than the resized image");
+    const int top = (int)__builtin_rint((Hr - crop) / 2.0), left = (int)__builtin_rint((Wr - crop) / 2.0);
+    resize_h_kernel<<<grid_for(h, (long long)B * H0 * crop, 256), 256, 0, h->stream>>>(hwc, B, H0, W0, Wr, left, crop, workspace);
+    resize_v_kernel<<<grid_for(h, (long long)B * crop * crop, 256), 256, 0, h->stream>>>(workspace, B, H0, Hr, top, crop, out_hwc);
+    LAUNCH_CHECK(h);
+    return IVIT_OK;
+}
+
 int ivit_normalize_quantize_u8(ivit_handle h, const uint8_t *hwc, int B, int H, int W, const float mean[3],
                                const float std_[3], float scale, int8_t *nchw) {
     CHECK_H(h);

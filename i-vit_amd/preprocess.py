@@ -25,3 +25,22 @@ def normalize_quantize(u8_hwc, scale, mean=IMAGENET_DEFAULT_MEAN, std=IMAGENET_D
     handle(x.device).call("ivit_normalize_quantize_u8", ctypes.c_void_p(x.data_ptr()), B, H, W, m, s,
                           float(np.float32(scale)), ctypes.c_void_p(out.data_ptr()))
     return out
+
+
+def resize_center_crop(u8_hwc, size=256, crop=224):
+    """Resize(size, bicubic) + CenterCrop(crop) on the device (utils/data_utils.py:82-88; the reference uses
+    size = int(crop / 0.875)): uint8 [B, H0, W0, 3] -> uint8 [B, crop, crop, 3]."""
+    if u8_hwc.dtype != torch.uint8 or u8_hwc.dim() != 4 or u8_hwc.shape[-1] != 3:
+        raise TypeError("expected a uint8 tensor [B, H, W, 3]")
+    x = u8_hwc.contiguous()
+    B, H0, W0, _ = x.shape
+    ws = torch.empty(B * H0 * crop * 3, dtype=torch.float32, device=x.device)
+    out = torch.empty(B, crop, crop, 3, dtype=torch.uint8, device=x.device)
+    handle(x.device).call("ivit_resize_center_crop_u8", ctypes.c_void_p(x.data_ptr()), B, H0, W0, int(size), int(crop),
+                          ctypes.c_void_p(ws.data_ptr()), ctypes.c_void_p(out.data_ptr()))
+    return out
+
+
+def eval_transform(u8_hwc, scale, size=256, crop=224):
+    """the whole eval transform of the reference on the device: resize -> centre crop -> ToTensor -> Normalize -> input QuantAct"""
+    return normalize_quantize(resize_center_crop(u8_hwc, size, crop), scale)

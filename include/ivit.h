@@ -63,9 +63,17 @@ int ivit_quantize_input_f32(ivit_handle h, const float *x, float scale, int8_t *
 /* ToTensor -> Normalize(mean, std) -> the same input QuantAct, from uint8 pixels on the device
  * (utils/data_utils.py:89-91: transforms.ToTensor, transforms.Normalize; then vit_quant.py:257):
  * hwc uint8 [B, H, W, 3] (a centre-cropped image as PIL hands it over) -> nchw int8 [B, 3, H, W].
- * mean / std are HOST arrays of 3 floats.  Resize / crop stay on the host.       */
+ * mean / std are HOST arrays of 3 floats.  Resize / crop: ivit_resize_center_crop_u8 below.       */
 int ivit_normalize_quantize_u8(ivit_handle h, const uint8_t *hwc, int B, int H, int W, const float mean_host[3],
                                const float std_host[3], float scale, int8_t *nchw);
+
+/* Resize(size, interpolation=bicubic) + CenterCrop(crop) of the same eval transform (utils/data_utils.py:82-88) on the
+ * device: hwc uint8 [B, H0, W0, 3] -> out_hwc uint8 [B, crop, crop, 3] (feed it to ivit_normalize_quantize_u8).  The
+ * shorter side is resized to `size` (the longer to int(size * long / short)), antialiased separable bicubic (a = -0.5)
+ * in fp32, rne, clamp; then the centre crop.  workspace: B * H0 * crop * 3 floats (caller-owned).  The reference resizes
+ * with PIL, which this image does not have: the pin is torch's antialiased bicubic (tests/golden/resize.npz).       */
+int ivit_resize_center_crop_u8(ivit_handle h, const uint8_t *hwc, int B, int H0, int W0, int size, int crop,
+                               float *workspace, uint8_t *out_hwc);
 
 /* ---- a1  QuantLinear.forward  (quant_modules.py:67-97) — integer accumulators.
  * acc[i,j] = sum_k x[i,k]*w[j,k] + bias[j];  x int8 [M,K], w int8 [N,K], K % 16 == 0. */

@@ -1114,3 +1114,27 @@ def test_imported_reference_swin_state_dict_runs_to_golden_logits():
               if type(mod) is iv.QuantAct and float(mod.act_scaling_factor.reshape(-1)[0]) > 0}
     eng = SwinEngine(cfg, w, scales)
     assert np.array_equal(eng.forward(dev(imgs)).cpu().numpy(), g["logits_int"])
+
+
+def test_device_resize_center_crop_equals_oracle(H):
+    """N3: ivit_resize_center_crop_u8 == the CPU restatement bit for bit (down- and up-scaling, portrait and landscape,
+    batch > 1), and the whole eval transform (resize -> crop -> ToTensor -> Normalize -> input QuantAct) on the device
+    equals the same chain built from the oracle's resize and torch's fp32 normalisation."""
+    from oracle import oracle as orc
+    from ivit_amd import preprocess as pp
+    g = load_golden("resize.npz")
+    for ci in range(int(g["n"])):
+        size, crop = [int(v) for v in g[f"cfg/{ci}"]]
+        img = np.concatenate([g[f"in/{ci}"], g[f"in/{ci}"][:, ::-1].copy()])       # batch of 2 (second one flipped)
+        got = pp.resize_center_crop(dev(img), size, crop).cpu().numpy()
+        assert np.array_equal(got, orc.resize_center_crop_u8(img, size, crop)), ci
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (3, 300, 400, 3), dtype=np.uint8)
+    s_in = np.float32(0.0207)
+    q = pp.eval_transform(dev(img), s_in, 256, 224).cpu().numpy()
+    crop = orc.resize_center_crop_u8(img, 256, 224)
+    x = torch.from_numpy(crop).permute(0, 3, 1, 2).float() / 255.0
+    mean = torch.tensor(pp.IMAGENET_DEFAULT_MEAN).view(1, 3, 1, 1)
+    std = torch.tensor(pp.IMAGENET_DEFAULT_STD).view(1, 3, 1, 1)
+    ref = torch.clamp(torch.round((1.0 / torch.tensor(s_in)) * ((x - mean) / std)), -128, 127).to(torch.int8).numpy()
+    assert np.array_equal(q, ref)

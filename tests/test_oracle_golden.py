@@ -162,3 +162,22 @@ def test_shiftmax_tables_reproduce_oracle_shiftmax():
             got = np.floor(((e * F[:, None]).astype(np.float32)) * np.float32(2.0 ** -16)).astype(np.int64)
             assert np.array_equal(got, ref), (scale, n)
     assert iv.freeze.shiftmax_tables(np.float32(0.2306), max_bytes=4096) is None      # 57 classes x 54 do not fit 4 KB
+
+
+def test_resize_center_crop_oracle_vs_torch_fixture():
+    """N3: the restated antialiased bicubic resize + centre crop (oracle.resize_center_crop_u8) against torch's
+    F.interpolate(mode="bicubic", antialias=True) outputs stored in tests/golden/resize.npz (the reference's PIL is not
+    in this image).  ATen's vectorised accumulation order is not restated, so the pin is: never more than 1 LSB apart,
+    and apart on fewer than 1e-3 of the pixels (rounding ties of the final rne)."""
+    from oracle import oracle as orc
+    g = load_golden("resize.npz")
+    total = diff = 0
+    for ci in range(int(g["n"])):
+        size, crop = [int(v) for v in g[f"cfg/{ci}"]]
+        got = orc.resize_center_crop_u8(g[f"in/{ci}"], size, crop)
+        ref = g[f"out/{ci}"]
+        d = np.abs(got.astype(np.int32) - ref.astype(np.int32))
+        assert d.max() <= 1, ci
+        total += d.size
+        diff += int((d > 0).sum())
+    assert diff <= 1e-3 * total, (diff, total)
