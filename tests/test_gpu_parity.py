@@ -1138,3 +1138,53 @@ def test_device_resize_center_crop_equals_oracle(H):
     std = torch.tensor(pp.IMAGENET_DEFAULT_STD).view(1, 3, 1, 1)
     ref = torch.clamp(torch.round((1.0 / torch.tensor(s_in)) * ((x - mean) / std)), -128, 127).to(torch.int8).numpy()
     assert np.array_equal(q, ref)
+
+
+@pytest.mark.parametrize("T,kind", [(197, "spread"), (197, "peaky"), (197, "saturated"), (577, "spread"), (577, "peaky"), (50, "saturated")])
+def test_fused_attention_core_vs_oracle(H, T, kind):
+    """the fused attention kernels against the CPU ORACLE directly (not against the unfused HIP chain):
+    q.k^T -> qact_attn1 -> Shiftmax(16) -> attn.v -> qact2 (vit_quant.py:70-83) at the token counts of the 224- and
+    384-pixel models, with score rows spread over the int8 range, peaky rows (one dominant key: the factor flips) and
+    saturated rows (many scores clamped at +-127/-128); both the arithmetic and the table-driven Shiftmax variants."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(T + len(kind))
+    B, Hh, dh = 2, 2, 64
+    ld = (T + 15) // 16 * 16
+    q = rng.integers(-128, 128, (B * Hh, T, dh), dtype=np.int8)
+    k = rng.integers(-128, 128, (B * Hh, T, dh), dtype=np.int8)
+    v = rng.integers(-128, 128, (B * Hh, T, dh), dtype=np.int8)
+    scale = np.float32(0.1947)
+    if kind == "peaky":
+        k = (k.astype(np.int32) // 6).astype(np.int8)
+        for r in range(T):                     # every query has one key it matches strongly
+            k[:, (r * 7) % T, :] = q[:, r, :] // 2
+        s_acc = np.float32(9.0e-5)
+    elif kind == "saturated":
+        s_acc = np.float32(2.4e-3)             # rq(acc) overshoots int8 on most of the row
+    else:
+        s_acc = np.float32(2.2e-4)
+    dqk_h = iv.freeze.dyadic(s_acc, scale)
+    dpv_h = iv.freeze.dyadic(np.float32(2.0 ** -15 * 0.1), np.float32(0.05))
+    # ---- oracle: the four reference operators in sequence
+    acc = orc.bmm_nt_i8(q, k)                                            # [BH, T, T]
+    s8 = orc.requant(acc, orc.dyadic(s_acc, scale), 8).astype(np.int8)
+    if kind == "saturated":
+        assert (np.abs(s8.astype(np.int32)) >= 127).mean() > 0.3
+    p16 = orc.shiftmax(s8, scale, 16)
+    ctx = orc.bmm_av(p16, v)                                             # [BH, T, dh]
+    ref = orc.requant(ctx, orc.dyadic(np.float32(2.0 ** -15 * 0.1), np.float32(0.05)), 8)
+    ref = ref.reshape(B, Hh, T, dh).transpose(0, 2, 1, 3).reshape(B, T, Hh * dh)
+    # ---- HIP
+    vt = np.zeros((B * Hh, dh, ld), np.int8)
+    vt[:, :, :T] = v.transpose(0, 2, 1)
+    qd, kd, vd = dev(q), dev(k), dev(vt)
+    o1 = torch.full((B, T, Hh * dh), 9, dtype=torch.int8, device="cuda")
+    H.call("ivit_attention_fused", P(qd), P(kd), P(vd), dyv(dqk_h), float(scale), dyv(dpv_h), P(o1), B, Hh, T, dh, ld)
+    assert np.array_equal(o1.cpu().numpy().astype(np.int32), ref), (T, kind, "arithmetic")
+    tabs = iv.freeze.shiftmax_tables(scale)
+    assert tabs is not None
+    o2 = torch.full_like(o1, 9)
+    H.call("ivit_attention_fused_lut", P(qd), P(kd), P(vd), dyv(dqk_h), float(scale), P(dev(tabs["aq"])), P(dev(tabs["t"])),
+           P(dev(tabs["cls"])), int(tabs["NC"]), int(tabs["t"].size), int(tabs["dmin"]), dyv(dpv_h), P(o2), B, Hh, T, dh, ld)
+    assert np.array_equal(o2.cpu().numpy().astype(np.int32), ref), (T, kind, "tables")
+    assert len(np.unique(ref)) > 10
