@@ -1188,3 +1188,32 @@ def test_fused_attention_core_vs_oracle(H, T, kind):
            P(dev(tabs["cls"])), int(tabs["NC"]), int(tabs["t"].size), int(tabs["dmin"]), dyv(dpv_h), P(o2), B, Hh, T, dh, ld)
     assert np.array_equal(o2.cpu().numpy().astype(np.int32), ref), (T, kind, "tables")
     assert len(np.unique(ref)) > 10
+
+
+@pytest.mark.parametrize("M", [640, 1000])
+def test_mlp_fused_vs_oracle(H, M):
+    """ivit_mlp_fused against the CPU ORACLE directly (Mlp.forward, layers_quant.py:144-153 + the residual
+    QuantAct of the block): fc1 -> qact(8) -> ShiftGELU -> qact(8) -> fc2 -> qact(16) -> qact(16, + identity)."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(M + 1)
+    C, HD = 96, 384
+    x = rng.integers(-128, 128, (M, C), dtype=np.int8)
+    w1 = rng.integers(-128, 128, (HD, C), dtype=np.int8); b1 = rng.integers(-3000, 3000, HD).astype(np.int32)
+    w2 = rng.integers(-128, 128, (C, HD), dtype=np.int8); b2 = rng.integers(-3000, 3000, C).astype(np.int32)
+    s1 = (10 ** rng.uniform(-5.3, -4.9, HD)).astype(np.float32); s_h = np.float32(0.012)
+    s_gelu_in = np.float32(0.03); s_g = np.float32(0.02)
+    s2 = (10 ** rng.uniform(-5.6, -5.2, C)).astype(np.float32); s_t = np.float32(2e-4)
+    s_res, s_fin = np.float32(2.7e-4), np.float32(3.1e-4)
+    res = rng.integers(-30000, 30000, (M, C)).astype(np.int16)
+    # oracle chain (the GELU input scale of the kernel's table is s_gelu_in: the hidden int8 IS the GELU input)
+    h8 = orc.requant(orc.linear_i8(x, w1, b1), orc.dyadic(s1, s_h), 8).astype(np.int8)
+    g16 = orc.shiftgelu(h8, s_gelu_in)
+    g8 = orc.requant(g16.astype(np.int32), orc.dyadic(np.float32(s_gelu_in * np.float32(2.0 ** -7)), s_g), 8).astype(np.int8)
+    t = orc.requant(orc.linear_i8(g8, w2, b2), orc.dyadic(s2, s_t), 16)
+    ref = orc.requant(t, orc.dyadic(s_t, s_fin), 16, res.astype(np.int32), orc.dyadic(s_res, s_fin))
+    tab = torch.empty(65536, dtype=torch.int8, device="cuda")
+    H.call("ivit_shiftgelu_build_table", float(s_gelu_in), dyv(iv.freeze.dyadic(np.float32(s_gelu_in * np.float32(2.0 ** -7)), s_g)), P(tab))
+    out = torch.full((M, C), -7, dtype=torch.int16, device="cuda")
+    H.call("ivit_mlp_fused", P(dev(x)), P(dev(w1)), P(dev(b1)), P(dev(iv.freeze.dyadic(s1, s_h))), P(tab), P(dev(w2)), P(dev(b2)),
+           P(dev(iv.freeze.dyadic(s2, s_t))), dyv(iv.freeze.dyadic(s_t, s_fin)), dyv(iv.freeze.dyadic(s_res, s_fin)), P(dev(res)), P(out), M, C, HD)
+    assert np.array_equal(out.cpu().numpy().astype(np.int32), ref)
