@@ -512,6 +512,14 @@ __global__ __launch_bounds__(G3Cfg<ASTAT>::NT, 2) void gemm_ps_kernel(GemmArgs p
 #ifndef G3_TRACE
 #define G3_TRACE 0
 #endif
+// VALU instructions the scheduler is asked to place after each MFMA of an epilogue section (0: compiler's own order)
+#ifndef G3_SGB
+#define G3_SGB 12
+#endif
+// 1: the second-dispatched half of the workgroup (waves 4..7, the arbitration losers of each SIMD) runs at s_setprio 1
+#ifndef G3_PRIO
+#define G3_PRIO 1
+#endif
 #define GA_TRACE_BYTES (G3_TRACE ? 8 * 3 * 6 * 4 * 8 : 0)
 
 // wait until at most n (uniform, SGPR) vector-memory instructions of this wave are outstanding, and for all LDS
@@ -521,6 +529,7 @@ __global__ __launch_bounds__(G3Cfg<ASTAT>::NT, 2) void gemm_ps_kernel(GemmArgs p
 #define GA_W1(k) "s_waitcnt vmcnt(" #k ") lgkmcnt(0)\n\ts_branch .Lgaw%=\n\t"
 #define GA_W8(a, b, c, d, e, f, g, h) GA_W1(a) GA_W1(b) GA_W1(c) GA_W1(d) GA_W1(e) GA_W1(f) GA_W1(g) GA_W1(h)
 __device__ __forceinline__ void ga_wait_vm(int n) {
+    n = __builtin_amdgcn_readfirstlane(n);                         // scalar clamp (s_max / s_min)
     n = n < 0 ? 0 : (n > 47 ? 47 : n);
     const int off = __builtin_amdgcn_readfirstlane(n * 8 + 12);   // table starts 12 bytes after the s_getpc result
     asm volatile(
@@ -594,6 +603,7 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
     const int wm = wave >> 1, wn = wave & 1, half = lane >> 5;
     constexpr bool OUT8 = (EPI == EPI_RQ8_CH || EPI == EPI_QKV);
     constexpr bool RES = (EPI == EPI_RQ16_CH_RES);
+    if (G3_PRIO && wave >= 4) __builtin_amdgcn_s_setprio(1);
     const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
     const unsigned ring_lds = smem_lds + GA_PANEL, cst_lds = ring_lds + GA_RING;
 
@@ -696,7 +706,7 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
     auto trace = [&](int kt, int pt) __attribute__((always_inline)) {
         if (G3_TRACE && bid == 0 && lane == 0 && tr_unit >= 0 && tr_unit < 3) {
             unsigned long long *tb = reinterpret_cast<unsigned long long *>(smem + GA_SMEM);
-            tb[(wave * 3 + tr_unit) * 24 + kt * 4 + pt] = __builtin_readcyclecounter();
+            tb[(wave * 3 + tr_unit) * 24 + kt * 8 + pt] = __builtin_readcyclecounter();
         }
     };
     v4i resv[8];          // residual pieces in flight / waiting for their sub-tile's epilogue: [(j*2 + i)*2 + piece]
@@ -903,7 +913,7 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
                                  "+v"(resv[E_LO * 2 + 3]));
             }
             // lgkmcnt(0) (inside ga_wait_vm): a raw s_barrier does not wait for this wave's own LDS reads
-            if (G3_TRACE && HAS_CUR) trace(PP == 0 ? 2 : PP - 1, 3);     // belongs to the previous pair's record
+            if (G3_TRACE && HAS_CUR) trace(PP == 0 ? 2 : PP - 1, 6);     // belongs to the previous step's record
             if (HAS_CUR) __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
@@ -931,6 +941,7 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
                         }
                 }
                 mma4(fa0, fb0);
+                if (G3_TRACE) { __builtin_amdgcn_sched_barrier(0); trace(PP, 1); }
                 // load target: slices 4, 5 of this round (pair 0), slices 0..3 of the next round or of the next unit
                 const bool last_round = round + 1 == nrounds;
                 const bool to_next = PP != 0 && last_round;
@@ -946,21 +957,40 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
                 res_request(std::integral_constant<int, 2 * PP>{}, prev);
                 res_request(std::integral_constant<int, 2 * PP + 1>{}, prev);
             }
-            if (G3_TRACE && HAS_CUR) trace(PP, 1);
+            if (G3_TRACE && HAS_CUR) trace(PP, 2);
             asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
+            // inside a section with epilogue work: all LDS reads first (next fragments, this section's multipliers), then
+            // ONE MFMA followed by a run of requant VALU, four times — the issue pattern tools/ubench/overlap.hip measures
+            // (an in-order wave that issues its 4 MFMAs back to back sits ~200 cycles in the matrix pipe's queue before
+            // its first VALU instruction)
+            auto interleave = [&]() __attribute__((always_inline)) {
+                if (G3_SGB && HAS_CUR && E_N > 0) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, G3_SGB, 0);
+                    }
+                }
+            };
             // ---- S1
             if (HAS_CUR) { frag_load(ks, q2, fa0, fb0); mma4(fa1, fb1); }
             if constexpr (E_N > 0) epi_section(EX, EY, ETWO, 0);
+            interleave();
             __builtin_amdgcn_sched_barrier(0);
+            if (G3_TRACE && HAS_CUR) trace(PP, 3);
             // ---- S2
             if (HAS_CUR) { frag_load(ks, q3, fa1, fb1); mma4(fa0, fb0); }
             if constexpr (E_N > 0) epi_section(EX, EY, ETWO, 1);
+            interleave();
             __builtin_amdgcn_sched_barrier(0);
+            if (G3_TRACE && HAS_CUR) trace(PP, 4);
             // ---- S3
             if (HAS_CUR) mma4(fa1, fb1);
             if constexpr (E_N > 0) epi_section(EX, EY, ETWO, 2);
-            if (G3_TRACE && HAS_CUR) { __builtin_amdgcn_sched_barrier(0); trace(PP, 2); }
+            interleave();
+            if (G3_TRACE && HAS_CUR) { __builtin_amdgcn_sched_barrier(0); trace(PP, 5); }
         };
         kpair(std::integral_constant<int, 0>{});
         kpair(std::integral_constant<int, 1>{});
