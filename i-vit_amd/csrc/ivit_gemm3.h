@@ -135,6 +135,19 @@ __device__ __forceinline__ v4i g3_load16_async(const void *ptr) {
     return v;
 }
 
+// the same through a buffer resource: lanes whose offset is out of range (>= num_records) read zeros / store nothing,
+// so tile edges need neither a branch nor a scratch line
+#define GA_OOB 0x80000000u
+__device__ __forceinline__ v4i ga_bufload16_async(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, int imm) {
+    v4i v;
+    if (imm == 0) asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v) : "v"(voff), "s"(rsrc) : "memory");
+    else asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:16" : "=v"(v) : "v"(voff), "s"(rsrc) : "memory");
+    return v;
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ga_rsrc(const void *ptr) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(ptr), 0, 0x7ffffff0, 0x00020000);
+}
+
 // DMA of one 64-column slice of a 256-row A panel (ASTAT): 16 KB, two 16-byte pieces per thread, into the
 // XOR-swizzled [row][64] image the fragment reads expect (same image as g2_issue's)
 __device__ __forceinline__ void g3_issue_a256(const int8_t *A, int lda, int M, int row0, int k0, char *dst, int tid) {
@@ -565,12 +578,12 @@ __device__ __forceinline__ void ga_rq4(const int (&z)[4], double c0, double c1, 
     double t0, t1, t2, t3;
     const double mg = G3_MAGIC;
     if (FMA) {
-        asm("v_cvt_f64_i32 %0, %4\n\tv_cvt_f64_i32 %1, %5\n\tv_cvt_f64_i32 %2, %6\n\tv_cvt_f64_i32 %3, %7\n\t"
+        asm volatile("v_cvt_f64_i32 %0, %4\n\tv_cvt_f64_i32 %1, %5\n\tv_cvt_f64_i32 %2, %6\n\tv_cvt_f64_i32 %3, %7\n\t"
             "v_fma_f64 %0, %0, %8, %12\n\tv_fma_f64 %1, %1, %9, %12\n\tv_fma_f64 %2, %2, %10, %12\n\tv_fma_f64 %3, %3, %11, %12"
             : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
             : "v"(z[0]), "v"(z[1]), "v"(z[2]), "v"(z[3]), "v"(c0), "v"(c1), "v"(c2), "v"(c3), "v"(mg));
     } else {
-        asm("v_cvt_f64_i32 %0, %4\n\tv_cvt_f64_i32 %1, %5\n\tv_cvt_f64_i32 %2, %6\n\tv_cvt_f64_i32 %3, %7\n\t"
+        asm volatile("v_cvt_f64_i32 %0, %4\n\tv_cvt_f64_i32 %1, %5\n\tv_cvt_f64_i32 %2, %6\n\tv_cvt_f64_i32 %3, %7\n\t"
             "v_mul_f64 %0, %0, %8\n\tv_mul_f64 %1, %1, %9\n\tv_mul_f64 %2, %2, %10\n\tv_mul_f64 %3, %3, %11\n\t"
             "v_add_f64 %0, %0, %12\n\tv_add_f64 %1, %1, %12\n\tv_add_f64 %2, %2, %12\n\tv_add_f64 %3, %3, %12"
             : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
@@ -582,6 +595,13 @@ __device__ __forceinline__ void ga_rq4(const int (&z)[4], double c0, double c1, 
     o[3] = __double2loint(t3);
 }
 
+// Pure VALU work has no place of its own in the instruction stream: the compiler puts it next to its users, across
+// scheduling fences.  These empty volatile statements (ordered among themselves and with the fences) tie values to a
+// chunk: inputs pinned at the chunk's start, results at its end.
+#define GA_PIN1(a) asm volatile("" : "+v"(a))
+#define GA_PIN2(a, b) asm volatile("" : "+v"(a), "+v"(b))
+#define GA_PIN4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+
 struct GaUnit {
     int row0, col0;   // first token / channel
     int cb;           // constants buffer (0..2)
@@ -591,14 +611,14 @@ struct GaUnit {
 
 // one 1 KB piece of an operand slice by DMA: uniform 64-bit base + per-lane 32-bit offset (the saddr + voffset form:
 // no per-lane 64-bit address arithmetic), LDS destination = uniform base (M0) + lane * 16
-__device__ __forceinline__ void ga_dma16(const int8_t *base, unsigned voff, int imm, unsigned lds_uniform) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + (size_t)voff + imm),
+__device__ __forceinline__ void ga_dma16(const int8_t *sbase, unsigned voff, unsigned lds_uniform) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(sbase + (size_t)voff),
                                      (__attribute__((address_space(3))) void *)(size_t)lds_uniform, 16, 0, 0);
 }
 
-template <int EPI, bool FMA>
+template <int EPI, bool MULTI, bool FMA>
 __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
-    __shared__ __attribute__((aligned(16))) char smem[GA_SMEM + GA_TRACE_BYTES];
+    __shared__ __attribute__((aligned(128))) char smem[GA_SMEM + GA_TRACE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1, half = lane >> 5;
     constexpr bool OUT8 = (EPI == EPI_RQ8_CH || EPI == EPI_QKV);
@@ -616,7 +636,7 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
     const int nwg = gridDim.x, bid = blockIdx.x;
     const long long nunits = (long long)((p.M + 255) >> 8) * p.tiles_n;
     int u_first, u_end, u_step;
-    if (p.K == GA_BK * GA_NK) {
+    if (!MULTI) {
         const int rr = (nwg & 7) == 0 ? (bid & 7) * (nwg >> 3) + (bid >> 3) : bid;
         u_first = (int)(nunits * rr / nwg);
         u_end = (int)(nunits * (rr + 1) / nwg);
@@ -631,7 +651,6 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
 
     const int8_t *A = reinterpret_cast<const int8_t *>(p.A);
     const int8_t *B = p.B;
-    char *const dummy = reinterpret_cast<char *>(p.dummy) + lane * 16;    // where lanes outside the matrix store
 
     // ---- vector-memory bookkeeping (all uniform): `issued` counts this wave's VMEM instructions,
     // mark[k] = count right after the slices of k-step k (ring slot k) were requested
@@ -643,43 +662,44 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
     // (chunk = position ^ ((row >> 1) & 7): conflict-free ds_read_b128 for the MFMA fragments).  Per-lane byte offsets
     // (relative to A / B) are recomputed once per panel / per unit; a slice then costs a scalar M0 write and the
     // instruction itself.
-    unsigned a_off[4] = {0, 0, 0, 0}, w_off[2] = {0, 0};
-    auto piece_chunk = [&](int id) __attribute__((always_inline)) { return (((id & 7) ^ ((id >> 4) & 7)) * 16); };
-    auto set_panel = [&](int row0) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int id = tid + i * 512;
-            a_off[i] = (unsigned)min(row0 + (id >> 3), p.M - 1) * (unsigned)p.lda + piece_chunk(id);
-        }
-    };
-    auto set_wtile = [&](int col0) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int id = tid + i * 512;
-            w_off[i] = (unsigned)min(col0 + (id >> 3), p.N - 1) * (unsigned)p.ldb + piece_chunk(id);
-        }
-    };
+    int a_row0 = 0, w_col0 = 0;     // panel / channel tile the next slice requests belong to (uniform)
+    int late_ok = 0;                // 0 until the first barrier of the stream: the prologue requested all three slots
+    const int dma_q = (wave + (wave >> 2) * 2 + 3) & 3;     // this wave's section of a refill window
+    auto tid_once = [&]() __attribute__((always_inline)) { int t = tid; asm volatile("" : "+v"(t)); return t; };
+    // piece id = tid + 512 i: row = (tid >> 3) + 64 i, the same swizzled source chunk for every i.  Per-lane offsets are
+    // recomputed for every slice from an opaque copy of tid (a handful of VALU operations per k-step) instead of
+    // living in registers across the unit loop, which runs within a few registers of the 256 budget.
+    auto set_panel = [&](int row0) __attribute__((always_inline)) { a_row0 = row0; };
+    auto set_wtile = [&](int col0) __attribute__((always_inline)) { w_col0 = col0; };
     const unsigned dma_lane0 = wave * 1024;
     // K = nrounds * 384: a unit is `nrounds` rounds of 3 k-steps over the same 3 + 3 LDS slots.  With one round the A
     // slices are stationary (requested only by the first unit of a panel); with more they stream like the weights.
-    const int nrounds = p.K / (GA_BK * GA_NK);
+    const int nrounds = MULTI ? p.K / (GA_BK * GA_NK) : 1;
     auto issue_slice = [&](auto s_t, const GaUnit &u, const int round) __attribute__((always_inline)) {
         constexpr int S = decltype(s_t)::value;
         const int kb = round * (GA_BK * GA_NK) + S * GA_BK;
         if (!((G3_DBG & 1) && u.row0 + u.col0 != 0)) {
-            if (u.need_a || nrounds > 1) {
+            const int t = tid_once(), r = t >> 3, ck = ((t & 7) ^ ((t >> 4) & 7)) * 16;
+            // scalar slice bases, opaque so that the address stays (SGPR base) + (32-bit VGPR offset)
+            const int8_t *sa = A + kb, *sb = B + kb;
+            asm volatile("" : "+s"(sa), "+s"(sb));
+            if (MULTI || u.need_a) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) ga_dma16(A, a_off[i], kb, smem_lds + S * GA_ASLICE + i * 8192 + dma_lane0);
+                for (int i = 0; i < 4; ++i)
+                    ga_dma16(sa, (unsigned)min(a_row0 + r + i * 64, p.M - 1) * (unsigned)p.lda + ck,
+                             smem_lds + S * GA_ASLICE + i * 8192 + dma_lane0);
                 issued += 4;
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i) ga_dma16(B, w_off[i], kb, ring_lds + S * GA_WSTAGE + i * 8192 + dma_lane0);
+            for (int i = 0; i < 2; ++i)
+                ga_dma16(sb, (unsigned)min(w_col0 + r + i * 64, p.N - 1) * (unsigned)p.ldb + ck,
+                         ring_lds + S * GA_WSTAGE + i * 8192 + dma_lane0);
             issued += 2;
         }
         mark[S] = issued;
     };
     auto issue_consts = [&](int col0, int cb) __attribute__((always_inline)) {
-        g3_issue_consts(p, col0, smem + GA_PANEL + GA_RING + cb * G3_CONST_BYTES, wave, lane);
+        g3_issue_consts(p, col0, smem + GA_PANEL + GA_RING + cb * G3_CONST_BYTES, wave, tid_once() & 63);
         if (wave < 3) issued += 1;
         mark_cst = issued;
     };
@@ -687,18 +707,17 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
     // ---- MFMA fragment / constant addresses.  The LDS image is 148 KB but a DS instruction's immediate offset
     // stops at 64 KB: left alone, the compiler keeps one address register per (k-step, operand).  Opaque per-lane
     // bases reach every fragment with an immediate.
-    unsigned fa_lo[4], fa_hi[4], fw[4];          // per 32-column group q of a 128-column slice
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int ra = wm * 64 + (lane & 31), rw = wn * 64 + (lane & 31), ch = q * 2 + half;
-        fa_lo[q] = smem_lds + ra * 128 + ((ch ^ ((ra >> 1) & 7)) << 4);
-        fa_hi[q] = fa_lo[q] + 2 * GA_ASLICE;
-        fw[q] = ring_lds + rw * 128 + ((ch ^ ((rw >> 1) & 7)) << 4);
-        asm volatile("" : "+v"(fa_lo[q]), "+v"(fa_hi[q]), "+v"(fw[q]));
+    // Group q of a slice differs from group 0 only in chunk bits: address(q) = address(0) ^ (q << 5) (the image is
+    // 128-byte aligned), one VALU op per fragment pair instead of a resident register per (operand, q).
+    unsigned fa0, fw0;
+    {
+        const int ra = wm * 64 + (lane & 31), rw = wn * 64 + (lane & 31);
+        fa0 = smem_lds + ra * 128 + ((half ^ ((ra >> 1) & 7)) << 4);
+        fw0 = ring_lds + rw * 128 + ((half ^ ((rw >> 1) & 7)) << 4);
+        asm volatile("" : "+v"(fa0), "+v"(fw0));
     }
     unsigned pc_lds = cst_lds + (wn * 64 + half * 4) * 8;          // this lane's first multiplier, buffer 0
-    unsigned pb_lds = cst_lds + 1024 + (wn * 64 + half * 4) * 4;   // this lane's first bias word, buffer 0
-    asm volatile("" : "+v"(pc_lds), "+v"(pb_lds));
+    asm volatile("" : "+v"(pc_lds));
 
     const double cm = p.dy_main.m * p.dy_main.r, cr = p.dy_res.m * p.dy_res.r;
     const float rcpT = 1.0f / (float)(p.T > 0 ? p.T : 1);
@@ -711,10 +730,27 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
     };
     v4i resv[8];          // residual pieces in flight / waiting for their sub-tile's epilogue: [(j*2 + i)*2 + piece]
     (void)resv;
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    v2d cqv[2][2];        // multipliers of the next epilogue work: [quad slot][c01 | c23], requested at the END of the
+                          // section before (after their previous contents were consumed)
+    v4i fa[2][2], fb[2][2];   // MFMA fragments of section G: [G & 1][i | j]
+    // accumulators of a unit start at the bias (lane: channels 32j + 8g + 4*half + e)
+    auto bias_init = [&](v16i(&acc)[2][2], int cb) __attribute__((always_inline)) {
+        // this lane's first bias word: cst + 1024 + (wn * 64 + half * 4) * 4, from the multiplier address
+        const unsigned bads = ((pc_lds - cst_lds) >> 1) + cst_lds + 1024 + (unsigned)cb * G3_CONST_BYTES;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const v4i bv = ga_lds_read16(bads + j * 128 + g * 32);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { acc[0][j][g * 4 + e] = bv[e]; acc[1][j][g * 4 + e] = bv[e]; }
+            }
+    };
 
     // token row / channel column of this lane's 16-channel run in sub-tile (i, j) of a unit
-    auto sub_row = [&](const GaUnit &t, int i) __attribute__((always_inline)) { return t.row0 + wm * 64 + i * 32 + (lane & 31); };
-    auto sub_col = [&](const GaUnit &t, int j) __attribute__((always_inline)) { return t.col0 + wn * 64 + j * 32 + half * 16; };
+    auto sub_row = [&](const GaUnit &t, int i) __attribute__((always_inline)) { return t.row0 + wm * 64 + i * 32 + (tid_once() & 31); };
+    auto sub_col = [&](const GaUnit &t, int j) __attribute__((always_inline)) { return t.col0 + wn * 64 + j * 32 + ((tid_once() >> 1) & 16); };
 
     // ------------------------------------------------------------------------------------------------
     // one unit: K loop of `cur` into accC (HAS_CUR) with the epilogue of `prev` out of accP (HAS_PREV)
@@ -725,38 +761,43 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
         // ---- epilogue of `prev`, in pieces small enough to be dealt out between the MFMA groups of a pair.
         // Sub-tile C = (i = C & 1, j = C >> 1).  int8: four quads (requant + pack) and a finish (half-wave exchange +
         // one 16-byte store); int16: two pieces (two quads + exchange + residual requant-add + one store each).
-        typedef double v2d __attribute__((ext_vector_type(2)));
-        int dpk[2][4];     // packed dwords of the (up to two) int8 sub-tiles in flight in a pair
-        (void)dpk;
-        auto rq_quad = [&](auto c_t, int g, int (&o)[4]) __attribute__((always_inline)) {
+        // The work is cut into CHUNKS of a few VALU instructions, one per MFMA slot (slot = 4 G + m, 48 per round):
+        // the section issues MFMA, chunk, MFMA, chunk ... with scheduling fences in between — the pattern
+        // tools/ubench/overlap.hip measures (a wave that issues its MFMAs back to back and its VALU work afterwards
+        // leaves the matrix pipe idle for the whole VALU stretch: both waves of a SIMD run the same schedule).
+        //   int8 (slots 12 C + 3 g + ph of sub-tile C, quad g): ph 0 requant (cvt/fma) + multipliers of the next quad,
+        //        ph 1 clamp + pack, ph 2 (g == 3) half-wave exchange + 16-byte store
+        //   int16 (slots 14 + 4 k + ph of piece k = 2 C + h2, quads h2 and h2 + 2): ph 0 requant a, ph 1 pack a +
+        //        requant b, ph 2 pack b + exchange + residual dwords 0, 1, ph 3 residual dwords 2, 3 + store
+        int dpk[4];        // packed dwords of the int8 sub-tile in flight
+        int oq[4];         // requantised quad between its two chunks
+        int w16[2][2];     // packed int16 pairs of the piece in flight
+        v4i v16;           // the piece after the half-wave exchange
+        (void)dpk; (void)oq; (void)w16; (void)v16;
+        // multipliers of quad (C, g) of unit t -> cqv[slot]
+        auto cq_quad = [&](int slot, const GaUnit &t, int C, int g) __attribute__((always_inline)) {
+            const unsigned cads = pc_lds + (unsigned)t.cb * G3_CONST_BYTES + (C >> 1) * 256 + g * 64;
+            cqv[slot][0] = __builtin_bit_cast(v2d, ga_lds_read16(cads));
+            cqv[slot][1] = __builtin_bit_cast(v2d, ga_lds_read16(cads + 16));
+        };
+        auto rq_asm = [&](auto c_t, int g, const v2d (&c)[2], int (&o)[4]) __attribute__((always_inline)) {
             constexpr int C = decltype(c_t)::value, i = C & 1, j = C >> 1;
-            const unsigned cads = pc_lds + (unsigned)prev.cb * G3_CONST_BYTES + j * 256 + g * 64;
-            const v2d c01 = __builtin_bit_cast(v2d, ga_lds_read16(cads));
-            const v2d c23 = __builtin_bit_cast(v2d, ga_lds_read16(cads + 16));
             const int z[4] = {accP[i][j][g * 4], accP[i][j][g * 4 + 1], accP[i][j][g * 4 + 2], accP[i][j][g * 4 + 3]};
-            ga_rq4<FMA>(z, c01[0], c01[1], c23[0], c23[1], o);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = OUT8 ? min(max(o[e], -128), 127) : min(max(o[e], -32768), 32767);
+            ga_rq4<FMA>(z, c[0][0], c[0][1], c[1][0], c[1][1], o);
         };
-        auto epi8_quad = [&](auto c_t, auto slot_t, int g) __attribute__((always_inline)) {
-            int o[4];
-            rq_quad(c_t, g, o);
-            const unsigned w01 = __builtin_amdgcn_perm((unsigned)o[1], (unsigned)o[0], 0x0c0c0400u);
-            const unsigned w23 = __builtin_amdgcn_perm((unsigned)o[3], (unsigned)o[2], 0x0c0c0400u);
-            dpk[decltype(slot_t)::value][g] = (int)__builtin_amdgcn_perm(w23, w01, 0x05040100u);
-        };
-        auto epi8_finish = [&](auto c_t, auto slot_t) __attribute__((always_inline)) {
-            constexpr int C = decltype(c_t)::value, i = C & 1, j = C >> 1, SL = decltype(slot_t)::value;
+        auto epi8_finish = [&](auto c_t) __attribute__((always_inline)) {
+            constexpr int C = decltype(c_t)::value, i = C & 1, j = C >> 1;
             const int grow = sub_row(prev, i), gcol = sub_col(prev, j);
             const bool ok = grow < p.M && gcol < p.N;
             // lower half-wave: channels 0..15 of the token = {h0.d0, h1.d0, h0.d1, h1.d1}; upper: 16..31
-            ga_swap32(dpk[SL][0], dpk[SL][2]);
-            ga_swap32(dpk[SL][1], dpk[SL][3]);
-            const v4i v = {dpk[SL][0], dpk[SL][2], dpk[SL][1], dpk[SL][3]};
+            ga_swap32(dpk[0], dpk[2]);
+            ga_swap32(dpk[1], dpk[3]);
+            const v4i v = {dpk[0], dpk[2], dpk[1], dpk[3]};
             if (G3_DBG & 8) return;
+            typedef unsigned v4u __attribute__((ext_vector_type(4)));
             if constexpr (EPI == EPI_RQ8_CH) {
-                char *dst = ok ? reinterpret_cast<char *>(p.out) + (long long)grow * p.ldc + gcol : dummy;
-                *reinterpret_cast<v4i *>(dst) = v;
+                const unsigned off = ok ? (unsigned)grow * (unsigned)p.ldc + (unsigned)gcol : GA_OOB;
+                __builtin_amdgcn_raw_buffer_store_b128((v4u)v, ga_rsrc(p.out), off, 0, 0);
                 issued += 1;
             } else {
                 // q / k: [b, head, t, dh] — 16 channels of one head; v^T: [b, head, dh, ldv] byte scatter.
@@ -764,89 +805,95 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
                 // (D % 128 == 0, dh % 32 == 0: checked by the host), so which / head are uniform.
                 const int ucol = prev.col0 + wn * 64 + j * 32;
                 const int which = ucol / p.D, within = ucol - which * p.D;
-                const int head = within / p.dh, d0 = within - head * p.dh + half * 16;
+                const int head = within / p.dh, d0 = within - head * p.dh + ((tid_once() >> 1) & 16);
                 const int gr = ok ? grow : 0;
                 const int b = g3_div(gr, p.T, rcpT), t = gr - b * p.T;
-                const long long bh = (long long)b * p.H + head;
+                const unsigned bh = (unsigned)(b * p.H + head);
                 if (which < 2) {
-                    char *dst = reinterpret_cast<char *>(which == 0 ? p.q : p.k) + (bh * p.T + t) * p.dh + d0;
-                    *reinterpret_cast<v4i *>(ok ? dst : dummy) = v;
+                    const unsigned off = ok ? (bh * (unsigned)p.T + (unsigned)t) * (unsigned)p.dh + (unsigned)d0 : GA_OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128((v4u)v, ga_rsrc(which == 0 ? p.q : p.k), off, 0, 0);
                     issued += 1;
                 } else {
-                    char *dst = reinterpret_cast<char *>(p.vt) + (bh * p.dh + d0) * p.ldv + t;
+                    const unsigned off = ok ? (bh * (unsigned)p.dh + (unsigned)d0) * (unsigned)p.ldv + (unsigned)t : GA_OOB;
+                    const __amdgpu_buffer_rsrc_t rs = ga_rsrc(p.vt);
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        char *d1 = ok ? dst + (long long)e * p.ldv : dummy;
-                        *d1 = (char)(v[e >> 2] >> (8 * (e & 3)));
-                    }
+                    for (int e = 0; e < 16; ++e)
+                        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(v[e >> 2] >> (8 * (e & 3))), rs, off, e * p.ldv, 0);
                     issued += 16;
                 }
             }
         };
-        // int16 piece h2 of sub-tile C: quads g = h2 and h2 + 2.  lower half-wave: channels 8*h2 .. +7 =
-        // {h0.g(h2), h1.g(h2)}; upper half-wave: 16 + the same
-        auto epi16_piece = [&](auto c_t, int h2) __attribute__((always_inline)) {
-            constexpr int C = decltype(c_t)::value, i = C & 1, j = C >> 1;
-            const int grow = sub_row(prev, i), gcol = sub_col(prev, j);
-            const bool ok = grow < p.M && gcol < p.N;
-            char *dst = ok ? reinterpret_cast<char *>(p.out) + ((long long)grow * p.ldc + gcol) * 2 + h2 * 16 : dummy;
-            int w[2][2];
+        auto chunk8 = [&](auto s_t) __attribute__((always_inline)) {
+            constexpr int S = decltype(s_t)::value, C = S / 12, r = S % 12, g = r / 3, ph = r % 3, qi = C * 4 + g;
+            const std::integral_constant<int, C> c_t{};
+            if constexpr (ph == 0) {
+                if constexpr (qi + 1 < 16) cq_quad((qi + 1) & 1, prev, (qi + 1) >> 2, (qi + 1) & 3);
+                rq_asm(c_t, g, cqv[qi & 1], oq);
+            } else if constexpr (ph == 1) {
+                GA_PIN4(oq[0], oq[1], oq[2], oq[3]);
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                int o[4];
-                rq_quad(c_t, h2 + 2 * q, o);
-                w[q][0] = (int)__builtin_amdgcn_perm((unsigned)o[1], (unsigned)o[0], 0x05040100u);
-                w[q][1] = (int)__builtin_amdgcn_perm((unsigned)o[3], (unsigned)o[2], 0x05040100u);
-            }
-            ga_swap32(w[0][0], w[1][0]);
-            ga_swap32(w[0][1], w[1][1]);
-            v4i v = {w[0][0], w[0][1], w[1][0], w[1][1]};
-            if constexpr (RES) {
-                const v4i rs = h2 ? resv[C * 2 + 1] : resv[C * 2];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int t0 = (int)(short)(v[q] & 0xffff), t1 = v[q] >> 16;
-                    const int r0 = (int)(short)(rs[q] & 0xffff), r1 = rs[q] >> 16;
-                    int o0 = rq_fast(r0, cr) + rq_fast(t0, cm);
-                    int o1 = rq_fast(r1, cr) + rq_fast(t1, cm);
-                    o0 = min(max(o0, -32768), 32767);
-                    o1 = min(max(o1, -32768), 32767);
-                    v[q] = (o0 & 0xffff) | (o1 << 16);
-                }
-            }
-            if (!(G3_DBG & 8)) {
-                *reinterpret_cast<v4i *>(dst) = v;
-                issued += 1;
+                for (int e = 0; e < 4; ++e) oq[e] = min(max(oq[e], -128), 127);
+                const unsigned w01 = __builtin_amdgcn_perm((unsigned)oq[1], (unsigned)oq[0], 0x0c0c0400u);
+                const unsigned w23 = __builtin_amdgcn_perm((unsigned)oq[3], (unsigned)oq[2], 0x0c0c0400u);
+                dpk[g] = (int)__builtin_amdgcn_perm(w23, w01, 0x05040100u);
+                GA_PIN1(dpk[g]);
+            } else if constexpr (g == 3) {
+                GA_PIN4(dpk[0], dpk[1], dpk[2], dpk[3]);
+                epi8_finish(c_t);
             }
         };
-        // the epilogue work of a pair that finishes sub-tiles X (and Y, if TWO), dealt into three sections
-        auto epi_section = [&](auto x_t, auto y_t, auto two_t, int sec) __attribute__((always_inline)) {
-            constexpr bool TWO = decltype(two_t)::value;
-            const std::integral_constant<int, 0> S0{};
-            const std::integral_constant<int, 1> S1{};
-            if (G3_DBG & 4) return;
-            if constexpr (OUT8) {
-                if (TWO) {
-                    if (sec == 0) { epi8_quad(x_t, S0, 0); epi8_quad(x_t, S0, 1); epi8_quad(x_t, S0, 2); }
-                    if (sec == 1) { epi8_quad(x_t, S0, 3); epi8_finish(x_t, S0); epi8_quad(y_t, S1, 0); epi8_quad(y_t, S1, 1); }
-                    if (sec == 2) { epi8_quad(y_t, S1, 2); epi8_quad(y_t, S1, 3); epi8_finish(y_t, S1); }
+        auto pack16 = [&](int (&o)[4], int (&w)[2]) __attribute__((always_inline)) {
+            typedef short v2s __attribute__((ext_vector_type(2)));
+            w[0] = __builtin_bit_cast(int, (v2s)__builtin_amdgcn_cvt_pk_i16(o[0], o[1]));      // saturating
+            w[1] = __builtin_bit_cast(int, (v2s)__builtin_amdgcn_cvt_pk_i16(o[2], o[3]));
+        };
+        auto res_math = [&](auto c_t, int h2, int q) __attribute__((always_inline)) {
+            constexpr int C = decltype(c_t)::value;
+            const v4i rs = h2 ? resv[C * 2 + 1] : resv[C * 2];
+            const int t0 = (int)(short)(v16[q] & 0xffff), t1 = v16[q] >> 16;
+            const int r0 = (int)(short)(rs[q] & 0xffff), r1 = rs[q] >> 16;
+            int o0 = rq_fast(r0, cr) + rq_fast(t0, cm);
+            int o1 = rq_fast(r1, cr) + rq_fast(t1, cm);
+            typedef short v2s __attribute__((ext_vector_type(2)));
+            v16[q] = __builtin_bit_cast(int, (v2s)__builtin_amdgcn_cvt_pk_i16(o0, o1));
+        };
+        constexpr int S16 = 14;      // first slot of the int16 pieces (their residual lands with the step-0 wait)
+        auto chunk16 = [&](auto s_t) __attribute__((always_inline)) {
+            constexpr int S = decltype(s_t)::value;
+            if constexpr (S == S16 - 2) cq_quad(0, prev, 0, 0);
+            if constexpr (S >= S16 && S < S16 + 32) {
+                constexpr int k = (S - S16) >> 2, ph = (S - S16) & 3, C = k >> 1, h2 = k & 1, i = C & 1, j = C >> 1;
+                const std::integral_constant<int, C> c_t{};
+                if constexpr (ph == 0) {
+                    cq_quad(1, prev, C, h2 + 2);
+                    rq_asm(c_t, h2, cqv[0], oq);
+                } else if constexpr (ph == 1) {
+                    GA_PIN4(oq[0], oq[1], oq[2], oq[3]);
+                    pack16(oq, w16[0]);
+                    GA_PIN2(w16[0][0], w16[0][1]);
+                    if constexpr (k + 1 < 8) cq_quad(0, prev, (k + 1) >> 1, (k + 1) & 1);
+                    rq_asm(c_t, h2 + 2, cqv[1], oq);
+                } else if constexpr (ph == 2) {
+                    GA_PIN4(oq[0], oq[1], oq[2], oq[3]);
+                    pack16(oq, w16[1]);
+                    // lower half-wave: channels 8*h2 .. +7 = {h0.g(h2), h1.g(h2)}; upper half-wave: 16 + the same
+                    ga_swap32(w16[0][0], w16[1][0]);
+                    ga_swap32(w16[0][1], w16[1][1]);
+                    v16 = v4i{w16[0][0], w16[0][1], w16[1][0], w16[1][1]};
+                    if constexpr (RES) { res_math(c_t, h2, 0); res_math(c_t, h2, 1); }
+                    GA_PIN4(v16[0], v16[1], v16[2], v16[3]);
                 } else {
-                    if (sec == 0) { epi8_quad(x_t, S0, 0); }
-                    if (sec == 1) { epi8_quad(x_t, S0, 1); epi8_quad(x_t, S0, 2); }
-                    if (sec == 2) { epi8_quad(x_t, S0, 3); epi8_finish(x_t, S0); }
-                }
-            } else {
-                if (TWO) {
-                    if (sec == 0) epi16_piece(x_t, 0);
-                    if (sec == 1) { epi16_piece(x_t, 1); epi16_piece(y_t, 0); }
-                    if (sec == 2) epi16_piece(y_t, 1);
-                } else {
-                    if (sec == 1) epi16_piece(x_t, 0);
-                    if (sec == 2) epi16_piece(x_t, 1);
+                    GA_PIN4(v16[0], v16[1], v16[2], v16[3]);
+                    if constexpr (RES) { res_math(c_t, h2, 2); res_math(c_t, h2, 3); }
+                    const int grow = sub_row(prev, i), gcol = sub_col(prev, j);
+                    const bool ok = grow < p.M && gcol < p.N;
+                    const unsigned off = ok ? ((unsigned)grow * (unsigned)p.ldc + (unsigned)gcol) * 2 + h2 * 16 : GA_OOB;
+                    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+                    __builtin_amdgcn_raw_buffer_store_b128((v4u)v16, ga_rsrc(p.out), off, 0, 0);
+                    issued += 1;
                 }
             }
         };
-
         // residual of sub-tile C of unit `t`, in the epilogue's register layout; requested a pair before its epilogue,
         // inside the same straight-line body (a value an asm load is still filling must not cross a loop edge: the
         // register allocator may copy it)
@@ -854,9 +901,10 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
             constexpr int C = decltype(c_t)::value;
             const int grow = sub_row(t, C & 1), gcol = sub_col(t, C >> 1);
             const bool ok = grow < p.M && gcol < p.N;
-            const char *src = ok ? reinterpret_cast<const char *>(p.residual) + ((long long)grow * p.ldc + gcol) * 2 : dummy;
-            resv[C * 2] = g3_load16_async(src);
-            resv[C * 2 + 1] = g3_load16_async(ok ? src + 16 : dummy);
+            const unsigned off = ok ? ((unsigned)grow * (unsigned)p.ldc + (unsigned)gcol) * 2 : GA_OOB;
+            const __amdgpu_buffer_rsrc_t rs = ga_rsrc(p.residual);
+            resv[C * 2] = ga_bufload16_async(rs, off, 0);
+            resv[C * 2 + 1] = ga_bufload16_async(rs, off, 16);
             issued += 2;
             mark_res[C] = issued;
         };
@@ -864,137 +912,121 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
         // fragments of (k-step KT, 32-column half kk) and the 4 MFMAs that consume them
         auto frag_load = [&](auto kt_t, auto q_t, v4i (&a)[2], v4i (&b)[2]) __attribute__((always_inline)) {
             constexpr int KT = decltype(kt_t)::value, q = decltype(q_t)::value;
-            const unsigned sA = (KT < 2 ? fa_lo[q] + KT * GA_ASLICE : fa_hi[q]);
-            const unsigned sB = fw[q] + KT * GA_WSTAGE;
+            const unsigned sA = (fa0 ^ (q << 5)) + KT * GA_ASLICE;
+            const unsigned sB = (fw0 ^ (q << 5)) + KT * GA_WSTAGE;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 a[i] = ga_lds_read16(sA + i * 4096);
                 b[i] = ga_lds_read16(sB + i * 4096);
             }
         };
-        auto mma4 = [&](const v4i (&a)[2], const v4i (&b)[2]) __attribute__((always_inline)) {
-            if (G3_DBG & 2) return;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    accC[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b[j], a[i], accC[i][j], 0, 0, 0);
-        };
-
-        // ---- one PAIR of k-steps (K0 = 2P, K1 = 2P + 1) behind one barrier.  The barrier publishes the slices of
-        // both steps (requested two pairs ago) and frees the ring slots of the previous pair, which this pair's DMA
-        // requests refill for the pair after next: slices 4, 5 of this unit (pair 0) or 0..3 of the next (pairs 1, 2).
-        // The pair is four hand-ordered sections (scheduling fences between them, free scheduling inside):
-        //   S0: fragments of group 0 and 1 | 4 MFMAs | DMA requests, residual requests
-        //   S1: fragments of group 2 | 4 MFMAs | epilogue part 0      S2: fragments of group 3 | 4 MFMAs | part 1
-        //   S3: 4 MFMAs | epilogue part 2
-        // so that every MFMA group finds its fragments in registers and every section carries requant work to issue
-        // while its MFMAs run.
-        auto kpair = [&](auto p_t) __attribute__((always_inline)) {
-            constexpr int PP = decltype(p_t)::value;      // k-step (128 columns) of the round
-            // epilogue sub-tiles of `prev` finished in this pair: residual flavour 0,1 | 2,3 in pairs 1 | 2 (their
-            // residual pieces are requested a pair earlier, inside this body); else 0 | 1 | 2,3
-            constexpr int E_LO = RES ? (PP == 0 ? 0 : 2 * PP - 2) : (PP == 2 ? 2 : PP);
-            constexpr int E_N = !HAS_PREV ? 0 : (RES ? (PP == 0 ? 0 : 2) : (PP == 2 ? 2 : 1));
-            const std::integral_constant<int, E_LO> EX{};
-            const std::integral_constant<int, (E_LO + 1) & 3> EY{};
-            const std::integral_constant<bool, E_N == 2> ETWO{};
-            {
-                // slices of K1 (requested after K0's) landed; the residual pieces of the sub-tiles finished in this pair;
-                // at pair 0 the unit's constants (requested at pair 2 of the previous unit, AFTER this pair's slices)
-                int n = 1 << 20;
-                if (HAS_CUR) n = issued - mark[PP];
-                if (HAS_CUR && PP == 0 && round == 0) n = min(n, issued - mark_cst);
-                if (RES && E_N == 2) n = min(n, issued - mark_res[E_LO + 1]);
-                if (HAS_CUR || (RES && E_N == 2)) ga_wait_vm(n);
-                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if constexpr (RES && E_N == 2)     // tie the residual registers to the wait
-                    asm volatile("" : "+v"(resv[E_LO * 2]), "+v"(resv[E_LO * 2 + 1]), "+v"(resv[E_LO * 2 + 2]),
-                                 "+v"(resv[E_LO * 2 + 3]));
-            }
-            // lgkmcnt(0) (inside ga_wait_vm): a raw s_barrier does not wait for this wave's own LDS reads
-            if (G3_TRACE && HAS_CUR) trace(PP == 0 ? 2 : PP - 1, 6);     // belongs to the previous step's record
-            if (HAS_CUR) __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            if (G3_TRACE && HAS_CUR) { if (PP == 0) ++tr_unit; trace(PP, 0); }
-            const std::integral_constant<int, PP> ks{};
-            const std::integral_constant<int, 0> q0{};
-            const std::integral_constant<int, 1> q1{};
-            const std::integral_constant<int, 2> q2{};
-            const std::integral_constant<int, 3> q3{};
-            v4i fa0[2], fb0[2], fa1[2], fb1[2];
-            // ---- S0
+        // ---- one k-step (128 columns) = four SECTIONS of 4 MFMAs (one 32-column group each).  Everything a section
+        // consumes from the LDS was requested one section earlier, so no section waits for a read it has just issued:
+        //   section (PP, Q), G = 4 PP + Q:  request the fragments of the next section and the multipliers of section
+        //   G + 1's epilogue work | 4 MFMAs on the fragments requested by the previous section | epilogue work G of
+        //   `prev` (multipliers requested by the previous section).
+        // The step's barrier sits between Q = 2 and Q = 3: before it every wave has waited for its own DMA pieces of
+        // the NEXT step's slices and for its last fragment reads of THIS step's; after it Q = 3 requests the next
+        // step's first fragments and refills this step's ring slot (slice PP of the next round / unit).
+        // Epilogue schedule of `prev` over the 12 sections of round 0 — int8: sub-tile G / 3, quads {0, 1} | {2} |
+        // {3} + finish; int16 + residual: residual requests in sections 0, 1, piece G - 3 in sections 3..10.
+        auto section = [&](auto pp_t, auto q_t) __attribute__((always_inline)) {
+            constexpr int PP = decltype(pp_t)::value, Q = decltype(q_t)::value, G = PP * 4 + Q;
+            constexpr int KTN = Q == 3 ? (PP + 1) % GA_NK : PP, QN = (Q + 1) & 3;
+            if (G3_TRACE && HAS_CUR) { if (G == 0) ++tr_unit; trace(PP, Q); }
             if (HAS_CUR) {
-                frag_load(ks, q0, fa0, fb0);
-                frag_load(ks, q1, fa1, fb1);
-                if (PP == 0 && round == 0) {
-                    // the accumulators start at the bias (lane: channels 32j + 8g + 4*half + e)
-                    const unsigned bads = pb_lds + (unsigned)cur.cb * G3_CONST_BYTES;
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const v4i bv = ga_lds_read16(bads + j * 128 + g * 32);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) { accC[0][j][g * 4 + e] = bv[e]; accC[1][j][g * 4 + e] = bv[e]; }
-                        }
+                // Refill of ring slot SL (free once everybody passed step SL's barrier with its reads done) with slice SL
+                // of the next round / unit.  The waves take turns: wave w requests its pieces in section dma_q of the
+                // window [Q = 3 of step SL, Q = 2 of step SL + 1] — requested by all eight waves at once, the pieces queue
+                // in the CU's one address path and every wave sits ~300 cycles at its DMA instructions with its MFMAs
+                // unissued (timeline trace).  SIMD mates (w, w + 4) get different sections.
+                constexpr int SL = Q == 3 ? PP : (PP + 2) % GA_NK;
+                const bool last_round = !MULTI || round + 1 == nrounds;
+                if (Q == 3 && PP == 0) {
+                    if (last_round) {
+                        set_wtile(next.col0);
+                        if (MULTI || next.need_a) set_panel(next.row0);
+                    }
+                    late_ok = 1;
                 }
-                mma4(fa0, fb0);
-                if (G3_TRACE) { __builtin_amdgcn_sched_barrier(0); trace(PP, 1); }
-                // load target: slices 4, 5 of this round (pair 0), slices 0..3 of the next round or of the next unit
-                const bool last_round = round + 1 == nrounds;
-                const bool to_next = PP != 0 && last_round;
-                const GaUnit &lu = to_next ? next : cur;
-                const int lround = PP == 0 ? round : (last_round ? 0 : round + 1);
-                if (lu.valid) {
-                    if (PP == 1 && to_next) { set_wtile(lu.col0); if (lu.need_a || nrounds > 1) set_panel(lu.row0); }
-                    issue_slice(std::integral_constant<int, (PP + 2) % GA_NK>{}, lu, lround);
-                    if (PP == 2 && to_next) issue_consts(lu.col0, lu.cb);
-                }
-            }
-            if constexpr (RES && HAS_PREV && PP < 2) {
-                res_request(std::integral_constant<int, 2 * PP>{}, prev);
-                res_request(std::integral_constant<int, 2 * PP + 1>{}, prev);
-            }
-            if (G3_TRACE && HAS_CUR) trace(PP, 2);
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            // inside a section with epilogue work: all LDS reads first (next fragments, this section's multipliers), then
-            // ONE MFMA followed by a run of requant VALU, four times — the issue pattern tools/ubench/overlap.hip measures
-            // (an in-order wave that issues its 4 MFMAs back to back sits ~200 cycles in the matrix pipe's queue before
-            // its first VALU instruction)
-            auto interleave = [&]() __attribute__((always_inline)) {
-                if (G3_SGB && HAS_CUR && E_N > 0) {
-                    __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, G3_SGB, 0);
+                if (dma_q == Q) {
+                    if (Q != 3 && PP == 0) {
+                        // slot 2, freed by the previous round's (unit's) last barrier: slice 2 of THIS round
+                        if (late_ok) issue_slice(std::integral_constant<int, SL>{}, cur, round);
+                    } else {
+                        const GaUnit &lu = last_round ? next : cur;
+                        if (lu.valid) issue_slice(std::integral_constant<int, SL>{}, lu, last_round ? 0 : round + 1);
                     }
                 }
+                if (Q == 3 && PP == 0 && last_round && next.valid) issue_consts(next.col0, next.cb);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            auto slot = [&](auto m_t) __attribute__((always_inline)) {
+                constexpr int m = decltype(m_t)::value;
+                if (HAS_CUR && !(G3_DBG & 2))
+                    accC[m & 1][m >> 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[G & 1][m >> 1], fa[G & 1][m & 1], accC[m & 1][m >> 1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (m == 0) {
+                    // the next section's fragments, requested behind this section's first MFMA (whose operand wait then
+                    // does not cover them) and three MFMAs ahead of their use
+                    if (HAS_CUR) frag_load(std::integral_constant<int, KTN>{}, std::integral_constant<int, QN>{}, fa[(G + 1) & 1], fb[(G + 1) & 1]);
+                    if constexpr (RES && HAS_PREV && G < 2) {
+                        res_request(std::integral_constant<int, 2 * G>{}, prev);
+                        res_request(std::integral_constant<int, 2 * G + 1>{}, prev);
+                    }
+                }
+                if constexpr (HAS_PREV) {
+                    if (!(G3_DBG & 4)) {
+                        if constexpr (OUT8) chunk8(std::integral_constant<int, G * 4 + m>{});
+                        else chunk16(std::integral_constant<int, G * 4 + m>{});
+                    } else if constexpr ((G * 4 + m) % 12 == 11) {
+                        // ablation: no requant work, one raw store per sub-tile keeps the MFMAs alive
+                        constexpr int C = (G * 4 + m) / 12;
+                        typedef unsigned v4u __attribute__((ext_vector_type(4)));
+                        const v4u v = {(unsigned)accP[C & 1][C >> 1][0], (unsigned)accP[C & 1][C >> 1][5],
+                                       (unsigned)accP[C & 1][C >> 1][10], (unsigned)accP[C & 1][C >> 1][15]};
+                        __builtin_amdgcn_raw_buffer_store_b128(v, ga_rsrc(p.dummy), (unsigned)(tid_once() & 63) * 16, 0, 0);
+                        issued += 1;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             };
-            // ---- S1
-            if (HAS_CUR) { frag_load(ks, q2, fa0, fb0); mma4(fa1, fb1); }
-            if constexpr (E_N > 0) epi_section(EX, EY, ETWO, 0);
-            interleave();
+            slot(std::integral_constant<int, 0>{});
+            slot(std::integral_constant<int, 1>{});
+            slot(std::integral_constant<int, 2>{});
+            slot(std::integral_constant<int, 3>{});
+            if constexpr (HAS_CUR && G == 11) {
+                // for the next body: the first quad's multipliers; the next unit's bias into the drained accumulators
+                // (harmless before the last round)
+                if (OUT8) cq_quad(0, cur, 0, 0);
+                bias_init(accP, next.cb);
+            }
+            if (Q == 2) {
+                // the next step's slices (requested two steps ago), the residual pieces of the next four sections, at
+                // step 2 the next unit's constants; lgkmcnt(0): a raw s_barrier does not wait for this wave's own LDS reads
+                int n = 1 << 20;
+                if (HAS_CUR) n = issued - mark[(PP + 1) % GA_NK];
+                if (HAS_CUR && PP == 2) n = min(n, issued - mark_cst);
+                if (RES && HAS_PREV && PP < 2) n = min(n, issued - mark_res[2 * PP + 1]);
+                if (G3_TRACE && HAS_CUR) { __builtin_amdgcn_sched_barrier(0); trace(PP, 4); }
+                if (HAS_CUR || (RES && HAS_PREV && PP < 2)) ga_wait_vm(n);
+                if constexpr (RES && HAS_PREV && PP < 2)      // tie the residual registers to the wait
+                    asm volatile("" : "+v"(resv[PP * 4]), "+v"(resv[PP * 4 + 1]), "+v"(resv[PP * 4 + 2]), "+v"(resv[PP * 4 + 3]));
+                if (G3_TRACE && HAS_CUR) trace(PP, 5);
+                if (HAS_CUR) __builtin_amdgcn_s_barrier();
+            }
+            asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
-            if (G3_TRACE && HAS_CUR) trace(PP, 3);
-            // ---- S2
-            if (HAS_CUR) { frag_load(ks, q3, fa1, fb1); mma4(fa0, fb0); }
-            if constexpr (E_N > 0) epi_section(EX, EY, ETWO, 1);
-            interleave();
-            __builtin_amdgcn_sched_barrier(0);
-            if (G3_TRACE && HAS_CUR) trace(PP, 4);
-            // ---- S3
-            if (HAS_CUR) mma4(fa1, fb1);
-            if constexpr (E_N > 0) epi_section(EX, EY, ETWO, 2);
-            interleave();
-            if (G3_TRACE && HAS_CUR) { __builtin_amdgcn_sched_barrier(0); trace(PP, 5); }
         };
-        kpair(std::integral_constant<int, 0>{});
-        kpair(std::integral_constant<int, 1>{});
-        kpair(std::integral_constant<int, 2>{});
+        auto kstep = [&](auto pp_t) __attribute__((always_inline)) {
+            section(pp_t, std::integral_constant<int, 0>{});
+            section(pp_t, std::integral_constant<int, 1>{});
+            section(pp_t, std::integral_constant<int, 2>{});
+            section(pp_t, std::integral_constant<int, 3>{});
+        };
+        kstep(std::integral_constant<int, 0>{});
+        kstep(std::integral_constant<int, 1>{});
+        kstep(std::integral_constant<int, 2>{});
     };
 
     // ---- the unit stream, two accumulator sets alternating
@@ -1010,12 +1042,25 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
     };
     int u_cur = u_first;
     GaUnit cur = locate(u_cur, 0), prev = cur, next = locate(u_cur + u_step, 1);
-    // prologue: constants and the slices of pairs 0 and 1 of the first unit
+    v16i acc0[2][2], acc1[2][2];
+    // prologue: constants and all three slices of the first unit's round 0; its bias and first fragments
     set_panel(cur.row0);
     set_wtile(cur.col0);
     issue_consts(cur.col0, 0);
     issue_slice(std::integral_constant<int, 0>{}, cur, 0);
     issue_slice(std::integral_constant<int, 1>{}, cur, 0);
+    issue_slice(std::integral_constant<int, 2>{}, cur, 0);
+    ga_wait_vm(issued - mark[0]);       // constants and slice 0 (requested before slices 1, 2)
+    __builtin_amdgcn_s_barrier();
+    bias_init(acc0, 0);
+    {
+        const unsigned sA = fa0, sB = fw0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            fa[0][i] = ga_lds_read16(sA + i * 4096);
+            fb[0][i] = ga_lds_read16(sB + i * 4096);
+        }
+    }
     auto advance = [&]() __attribute__((always_inline)) {
         prev = cur;
         cur = next;
@@ -1023,19 +1068,18 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
         next = locate(u_cur + u_step, cur.cb == 2 ? 0 : cur.cb + 1);
         return cur.valid != 0;
     };
-    v16i acc0[2][2], acc1[2][2];
     const std::true_type T{};
     const std::false_type F{};
     // round 0 of a unit carries the previous unit's epilogue; rounds 1.. (K > 384) only multiply
     tile_body(T, F, acc0, acc1, cur, prev, next, 0);
-    for (int r = 1; r < nrounds; ++r) tile_body(T, F, acc0, acc1, cur, prev, next, r);
+    if (MULTI) for (int r = 1; r < nrounds; ++r) tile_body(T, F, acc0, acc1, cur, prev, next, r);
     for (;;) {
         if (!advance()) { tile_body(F, T, acc1, acc0, cur, prev, next, 0); break; }
         tile_body(T, T, acc1, acc0, cur, prev, next, 0);
-        for (int r = 1; r < nrounds; ++r) tile_body(T, F, acc1, acc0, cur, prev, next, r);
+        if (MULTI) for (int r = 1; r < nrounds; ++r) tile_body(T, F, acc1, acc0, cur, prev, next, r);
         if (!advance()) { tile_body(F, T, acc0, acc1, cur, prev, next, 0); break; }
         tile_body(T, T, acc0, acc1, cur, prev, next, 0);
-        for (int r = 1; r < nrounds; ++r) tile_body(T, F, acc0, acc1, cur, prev, next, r);
+        if (MULTI) for (int r = 1; r < nrounds; ++r) tile_body(T, F, acc0, acc1, cur, prev, next, r);
     }
     if (G3_TRACE && bid == 0) {
         __syncthreads();

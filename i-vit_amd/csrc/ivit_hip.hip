@@ -429,15 +429,21 @@ static int launch_gemm3(ivit_handle h, const ivit_linear_plan_s *pl, GemmArgs &a
     const bool fma = force_fma >= 0 ? (force_fma != 0 && pl->single_fma_ok) : (pl->single_fma_ok != 0);
     // A-stationary kernel: K == 384; the qkv scatter additionally needs whole units inside one of q / k / v and
     // whole 32-channel groups inside one head
-    const bool astat = astat_on && (a.K % (64 * GA_NK)) == 0 && a.M >= 256 && (a.N % 32) == 0 &&
+    const bool astat = astat_on && (a.K % (GA_BK * GA_NK)) == 0 && a.M >= 256 && (a.N % 32) == 0 &&
                        (long long)a.M * a.lda < (1LL << 32) && (long long)a.N * a.ldb < (1LL << 32) &&
                        (EPI != EPI_QKV || ((a.D % 128) == 0 && (a.dh % 32) == 0));
     if (astat) {
         const long long nunits = (long long)((a.M + 255) / 256) * a.tiles_n;
         long long grid = h->num_cu;
         if (grid > nunits) grid = nunits;
-        if (fma) gemm_as_kernel<EPI, true><<<dim3((unsigned)grid), 512, 0, h->stream>>>(a);
-        else gemm_as_kernel<EPI, false><<<dim3((unsigned)grid), 512, 0, h->stream>>>(a);
+        const dim3 g((unsigned)grid);
+        if (a.K == GA_BK * GA_NK) {
+            if (fma) gemm_as_kernel<EPI, false, true><<<g, 512, 0, h->stream>>>(a);
+            else gemm_as_kernel<EPI, false, false><<<g, 512, 0, h->stream>>>(a);
+        } else {
+            if (fma) gemm_as_kernel<EPI, true, true><<<g, 512, 0, h->stream>>>(a);
+            else gemm_as_kernel<EPI, true, false><<<g, 512, 0, h->stream>>>(a);
+        }
     } else {
         const long long nunits = (long long)((a.M + 127) / 128) * a.tiles_n;
         long long grid = (long long)h->num_cu * wg_per_cu;
