@@ -413,6 +413,9 @@ int ivit_linear_plan_query(ivit_linear_plan p, int *pipelined_ok, int *single_fm
 // scatter, 4 requant + residual; the others stay on the launch-per-tile kernels (A/B and fallback).
 static inline bool use_gemm3(const ivit_linear_plan_s *pl, const GemmArgs &a, int epi_bit) {
     static const int on = env_int("IVIT_GEMM3", 7);
+    // the residual flavour on a narrow output (N = 384: three channel tiles per 256-token panel, 77 % balance, and its
+    // 32 resident residual registers) measured no better in-model than the launch-per-tile kernel: N >= 512 only
+    if (epi_bit == 4 && a.N < 512) return false;
     return (on & epi_bit) && pl->pipelined_ok && (a.K % 64) == 0 && a.K >= 320 && (a.N % 16) == 0 && (a.ldc % 16) == 0 &&
            (a.lda % 16) == 0 && (a.ldb % 16) == 0 && a.M >= 128;
 }
