@@ -1,46 +1,29 @@
-// ivit_gemm3.h — persistent, software-pipelined int8 GEMMs for the QuantLinear layers
-// (K % 64 == 0, K >= 320, N % 16 == 0): the production kernels of the DeiT/ViT path.
+// ivit_gemm3.h — persistent, software-pipelined int8 GEMMs for the QuantLinear layers: the production kernels of the
+// DeiT / ViT path (planned entry points of include/ivit.h; dispatch in ivit_hip.hip, launch_gemm3).
 //
-//   C = A (M x K int8) * W^T (W: N x K int8) + bias, fused requant epilogues (a1 + a3 [+ a3 identity]).
+//   C = A (M x K int8) * W^T (W: N x K int8) + bias, fused requant epilogues (a1 + a3 [+ a3 identity] [+ qkv scatter]).
 //
-// Why: at K = 384 a 128 x 128 tile is 48 MFMAs per wave.  A launch-per-tile kernel spends as long waiting
-// for its first operands and running its requant epilogue as it spends in MFMAs, and — measured with the
-// ablation switches below — the operand stream alone (global_load_lds, L2 -> LDS) of a 128- or 256-row
-// tiling takes 41 us of fc1's 55: ~11 TB/s is what the chip's L2 -> LDS path delivers, and 1/64 B per MAC
-// is more than an int8 MFMA GEMM can afford.  One kernel template, two modes:
-//
-//   * ASTAT = true (K <= 384: qkv, proj, fc1) — A-STATIONARY.  One workgroup per CU (8 waves, 256
-//     registers each) owns a contiguous range of (256-token panel, 128-channel tile) units.  The panel
-//     (256 x K int8 = 96 KB) stays in LDS; its 64-column slices arrive lazily, together with the weight
-//     slices, during the panel's first unit.  Every later unit of the panel streams ONLY the 8 KB weight
-//     slice per k-step: 1/256 B per MAC instead of 1/64..1/85.
-//   * ASTAT = false (K > 384: fc2) — STREAMING.  Two workgroups per CU (4 waves each) walk lists of
-//     128 x 128 tiles; A and W slices both go through the ring.
+//   * gemm_as_kernel (K % 384 == 0, M >= 256, N % 32 == 0): one workgroup per CU (8 waves, 256 registers each) walks
+//     (256-token panel, 128-channel tile) units.  K == 384: the panel stays in LDS (A-stationary), only the weight tile
+//     streams; K = n * 384: n rounds over the same LDS slots, A streams like the weights.  Described at the kernel.
+//   * gemm_ps_kernel (everything else the planned path accepts: K % 64 == 0, K >= 320): two workgroups per CU walk
+//     128 x 128 tiles, A and W through a 3-deep ring, LDS-staged output tile.  The first persistent design, kept as
+//     the general-shape kernel.
 //
 // Common to both:
-//   * persistent: the (unit, k-step) sequence of a workgroup is ONE stream; operand slices arrive by
-//     global_load_lds into a 3-deep LDS ring that runs two k-steps ahead ACROSS unit boundaries, so only
-//     the first unit of a workgroup ever waits for a cold load;
-//   * software-pipelined epilogue: two accumulator sets.  While the MFMAs of unit i+1 fill one set, the
-//     requant arithmetic of unit i drains the other in the same instruction stream, one 32 x 32 sub-tile
-//     per k-step — VALU work issued between MFMAs instead of after them (tools/ubench/overlap.hip);
-//   * the bias is the MFMA C operand of a unit's first k-step (no add in the epilogue); the per-channel
-//     multipliers c = m * 2^-e come precomputed from the linear plan (ivit_linear_plan_create), which
-//     also PROVES per channel, from sum_k |W[n,k]|, that rne((acc + bias) * c) may be taken as the low
-//     dword of fma(double(z), c, 1.5 * 2^52): one v_cvt_f64_i32 + one v_fma_f64 per output element;
-//   * every other vector-memory instruction of the epilogue (output stores, the residual loads) is issued
-//     right BEFORE a k-step's operand DMA, so the counted `s_waitcnt vmcnt(n)` of the next step retires it
-//     together with the operands it has to wait for anyway and never drains the ring (n = the DMA
-//     instructions of the newest step: loads return in order).
+//   * persistent: the (unit, k-step) sequence of a workgroup is ONE stream; operand slices arrive by global_load_lds
+//     into an LDS ring that runs two k-steps ahead ACROSS unit boundaries — only the first unit waits for a cold load;
+//   * two accumulator sets: while the MFMAs of unit i+1 fill one, the requant arithmetic of unit i drains the other in
+//     the same instruction stream;
+//   * the bias is the accumulators' initial value; the per-channel multipliers c = m * 2^-e come precomputed from the
+//     linear plan (ivit_linear_plan_create), which also PROVES per channel, from sum_k |W[n,k]|, that
+//     rne((acc + bias) * c) may be taken as the low dword of fma(double(z), c, 1.5 * 2^52): one v_cvt_f64_i32 + one
+//     v_fma_f64 per output element (FMA = true), or v_mul_f64 + v_add_f64 when only the product bound holds;
+//   * exact `s_waitcnt vmcnt(n)`: vector-memory instructions retire in issue order, so "slice s has landed" is a
+//     count of the instructions issued after it; stores and residual loads never drain the ring.
 //
-// LDS (ASTAT): panel 96 KB | weight ring 3 x 8 KB | staged output tile 34 KB (int8: 256 x 128; int16: two
-// 64-channel halves) | per-unit constants 2 x 1.5 KB (double-buffered: unit i's multipliers are still in
-// use while unit i+1's bias is loaded) = 157 KB.  Streaming: ring 3 x 16 KB | 17 KB | 3 KB = 68 KB.
-//
-// Arithmetic (bit-exact restatement of quant_utils.py:229-231, see ivit_gemm2.h): swapped MFMA operands
-// (weights = "A"), so a lane holds one token and 4 consecutive channels per register quad.
-// Ablation (env IVIT_GEMM3_DBG, timing only, results invalid): 1 = no operand DMA after the first unit,
-// 2 = no LDS fragment reads / MFMAs, 4 = no epilogue arithmetic, 8 = no output stores (RQ8 epilogue).
+// Arithmetic (bit-exact restatement of quant_utils.py:229-231, see ivit_gemm2.h): swapped MFMA operands (weights =
+// "A"), so a lane holds one token and 4 consecutive channels per register quad.
 #pragma once
 #include "ivit_gemm2.h"
 
@@ -490,27 +473,34 @@ __global__ __launch_bounds__(G3Cfg<ASTAT>::NT, 2) void gemm_ps_kernel(GemmArgs p
 }
 
 // =====================================================================================================
-// gemm_as_kernel — A-stationary, K = 384 (6 k-steps): qkv, proj, fc1 of the D = 384 models.
+// gemm_as_kernel — K = n * 384: every QuantLinear of the D = 384 / 768 models.
 //
-// Measured on the first A-stationary version (3-deep weight ring, LDS-staged epilogue; IVIT_GEMM3_DBG):
-// with MFMAs, epilogue and stores all switched off, fc1's loop of {wait for the weight slice, barrier,
-// request the slice two steps ahead} still took 25 us — a global_load_lds takes ~0.85 us from issue to
-// landing, so a ring that runs two steps ahead makes every k-step last half that latency no matter how
-// little it computes.  This kernel spends the LDS on prefetch depth instead of on a staged output tile:
+// LDS (148.5 KB): A panel 3 x 32 KB (256 tokens x 128-column slice) | weight ring 3 x 16 KB (128 channels x 128
+// columns; slot == k-step index) | constants 3 x 1.5 KB (unit i-1's multipliers are in use during unit i, whose first
+// step already requests unit i+1's).  A unit is 3 k-steps of 128 columns (n rounds of them for K = n * 384); a k-step is
+// four SECTIONS of 4 MFMAs per wave (8 waves as 4 (tokens) x 2 (channels), 64 x 64 per wave).
 //
-//   LDS: panel 6 x 16 KB (stationary A slices) | weight ring 6 x 8 KB (one whole unit, requested two PAIRS of
-//        k-steps ahead: one barrier per pair; ring slot == k-step index) | constants 3 x 1.5 KB                 = 148.5 KB
-//        (unit i-1's multipliers are in use until step 5 of unit i, whose step 4 already requests unit i+1's)
-//   * epilogue without LDS: a lane's 4 packed dwords of a 32 x 32 sub-tile (4-channel runs at 8g + 4*half)
-//     become 16 consecutive channels of one token with two v_permlane32_swap — straight 16-byte stores
-//     (int8) or 2 x 16 bytes (int16); the residual is loaded in the same layout, so the identity
-//     requant-add happens in registers;
-//   * exact wait counts: vector-memory instructions retire in issue order (loads AND stores: the compiler's
-//     own gfx9 wait-count model relies on it), so "the slice of step s has landed" is
-//     `s_waitcnt vmcnt(#instructions issued after it)`.  Every such instruction is issued unconditionally
-//     (lanes outside the matrix store to a scratch line), the running count lives in SGPRs, and the wait
-//     is picked from a jump table of immediates.  Stores and residual loads therefore never hold up the
-//     operand stream, wherever they are issued.
+// What the timeline trace (G3_TRACE, tools/gemm3_trace.py) and the ablation builds said, and what the kernel does
+// about it (profiles/README.md has the numbers):
+//   * a global_load_lds takes ~0.85 us from issue to landing: the ring runs two k-steps ahead, across unit boundaries;
+//   * a section that reads fragments or multipliers from the LDS and uses them at once stalls ~200 cycles with at most
+//     one MFMA in flight: everything a section consumes is requested one section earlier, and the step's barrier sits
+//     between sections 2 and 3, so that section 3 can already request the next step's first fragments;
+//   * eight waves requesting their DMA pieces at once queue in the CU's one address path (~300 cycles at the DMA
+//     instructions, MFMAs unissued): the waves take turns, one section apart (SIMD mates in different sections);
+//   * pure VALU work has no place of its own in the compiler's schedule — it drifted next to its users, leaving
+//     MFMA MFMA MFMA MFMA, then all the requant work with the matrix pipe idle: the epilogue is cut into ~8-instruction
+//     CHUNKS, one behind each MFMA, pinned by empty volatile statements and scheduling fences;
+//   * epilogue without LDS: a lane's 4 packed dwords of a 32 x 32 sub-tile (4-channel runs at 8g + 4*half) become 16
+//     consecutive channels of one token with two v_permlane32_swap — straight 16-byte buffer stores (range-checked:
+//     tile edges need no branch); the residual is loaded in the same layout, requant-add in registers;
+//   * 256 registers hold two accumulator sets (128), double-buffered fragments (32), the residual pieces (32, int16 +
+//     residual flavour only) and little else: per-lane addresses are recomputed from an opaque copy of the thread id
+//     at each use instead of living across the unit loop.
+// Where it stands (fc1, 50432 x 1536 x 384): 45.6 us = 1.30 POP/s.  The matrix pipe sustains 47 cycles per MFMA on
+// random int8 data and the fp64 requant costs ~19 SIMD-cycles per 64 outputs that do NOT hide behind MFMAs of the
+// other wave (tools/ubench/overlap.hip: 46.6 cycles per MFMA alone, 72 with this kernel's 1.33 outputs per MFMA):
+// ~2300 cycles per k-step are the instruction mix's own floor, ~2800 are measured.
 #define GA_NK 3                       // k-steps of 128 columns per round (K = 384 per round)
 #define GA_BK 128
 #define GA_ASLICE 32768               // 256 tokens x 128 B
@@ -519,19 +509,16 @@ __global__ __launch_bounds__(G3Cfg<ASTAT>::NT, 2) void gemm_ps_kernel(GemmArgs p
 #define GA_RING (GA_NK * GA_WSTAGE)
 #define GA_SMEM (GA_PANEL + GA_RING + 3 * G3_CONST_BYTES)
 // timeline instrumentation (compile time, -DG3_TRACE=1 into a scratch library): wave w of workgroup 0 stamps
-// s_memtime at four points of every k-step of its units 2..4 into LDS and dumps them behind the plan's store
-// scratch (read back with ivit_debug_plan_scratch).  Points: 0 after the barrier, 1 after the DMA requests,
-// 2 after the MFMA + epilogue block, 3 after the counted wait (before the next barrier).
+// s_memtime at six points of every k-step of three units into LDS and dumps them behind the plan's store
+// scratch (read back with ivit_debug_plan_scratch).  Points 0..3: start of section 0..3; 4 / 5: before / after the
+// counted wait (the barrier follows 5).  The stamps themselves cost ~80 cycles each.
 #ifndef G3_TRACE
 #define G3_TRACE 0
 #endif
-// VALU instructions the scheduler is asked to place after each MFMA of an epilogue section (0: compiler's own order)
-#ifndef G3_SGB
-#define G3_SGB 12
-#endif
-// 1: the second-dispatched half of the workgroup (waves 4..7, the arbitration losers of each SIMD) runs at s_setprio 1
+// 1: waves 4..7 run at s_setprio 1.  Zero-sum (timeline trace): whichever SIMD mate has the priority finishes its
+// step ~500 cycles earlier and waits that much longer at the barrier; kept as a switch for experiments.
 #ifndef G3_PRIO
-#define G3_PRIO 1
+#define G3_PRIO 0
 #endif
 #define GA_TRACE_BYTES (G3_TRACE ? 8 * 3 * 6 * 4 * 8 : 0)
 
