@@ -520,6 +520,10 @@ __global__ __launch_bounds__(G3Cfg<ASTAT>::NT, 2) void gemm_ps_kernel(GemmArgs p
 #ifndef G3_PRIO
 #define G3_PRIO 0
 #endif
+// 1: counted waits through the jump table (exact); 0: two inline levels (ga_wait_vm_fast)
+#ifndef G3_WAIT_TABLE
+#define G3_WAIT_TABLE 0
+#endif
 #define GA_TRACE_BYTES (G3_TRACE ? 8 * 3 * 6 * 4 * 8 : 0)
 
 // wait until at most n (uniform, SGPR) vector-memory instructions of this wave are outstanding, and for all LDS
@@ -541,6 +545,25 @@ __device__ __forceinline__ void ga_wait_vm(int n) {
         GA_W8(24, 25, 26, 27, 28, 29, 30, 31) GA_W8(32, 33, 34, 35, 36, 37, 38, 39) GA_W8(40, 41, 42, 43, 44, 45, 46, 47)
         ".Lgaw%=:\n\t"
         :: "s"(off) : "vcc", "scc", "memory");
+}
+
+// The same with two inline levels instead of the table: s_waitcnt vmcnt(C) is right whenever n >= C (it only waits for a
+// few MORE of the older instructions than necessary), which is the steady state when C is the smallest count the stream
+// produces between a slice's request and its use; n >= C2 covers a workgroup's first unit, anything less waits for all.
+// Costs a wait, two compares and a short forward branch; the table costs two far jumps (~120 cycles on the timeline).
+template <int C, int C2>
+__device__ __forceinline__ void ga_wait_vm_fast(int n) {
+    n = __builtin_amdgcn_readfirstlane(n);
+    asm volatile(
+        "s_waitcnt vmcnt(%1) lgkmcnt(0)\n\t"
+        "s_cmp_ge_i32 %0, %1\n\t"
+        "s_cbranch_scc1 .Lgawf%=\n\t"
+        "s_waitcnt vmcnt(%2)\n\t"
+        "s_cmp_ge_i32 %0, %2\n\t"
+        "s_cbranch_scc1 .Lgawf%=\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        ".Lgawf%=:\n\t"
+        :: "s"(n), "n"(C), "n"(C2) : "scc", "memory");
 }
 
 // 16-byte LDS read at an explicit LDS byte address (one base register + immediate offset)
@@ -996,7 +1019,10 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
                 if (HAS_CUR && PP == 2) n = min(n, issued - mark_cst);
                 if (RES && HAS_PREV && PP < 2) n = min(n, issued - mark_res[2 * PP + 1]);
                 if (G3_TRACE && HAS_CUR) { __builtin_amdgcn_sched_barrier(0); trace(PP, 4); }
-                if (HAS_CUR || (RES && HAS_PREV && PP < 2)) ga_wait_vm(n);
+                if (HAS_CUR || (RES && HAS_PREV && PP < 2)) {
+                    if (G3_WAIT_TABLE) ga_wait_vm(n);
+                    else ga_wait_vm_fast<MULTI ? 8 : 4, MULTI ? 6 : 2>(n);
+                }
                 if constexpr (RES && HAS_PREV && PP < 2)      // tie the residual registers to the wait
                     asm volatile("" : "+v"(resv[PP * 4]), "+v"(resv[PP * 4 + 1]), "+v"(resv[PP * 4 + 2]), "+v"(resv[PP * 4 + 3]));
                 if (G3_TRACE && HAS_CUR) trace(PP, 5);
