@@ -664,7 +664,7 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
 
     // ---- vector-memory bookkeeping (all uniform): `issued` counts this wave's VMEM instructions,
     // mark[k] = count right after the slices of k-step k (ring slot k) were requested
-    int issued = 0, mark[GA_NK] = {0, 0, 0}, mark_res[4] = {0, 0, 0, 0}, mark_cst = 0;
+    int issued = 0, mark[GA_NK] = {0, 0, 0}, mark_res[2] = {0, 0}, mark_cst = 0;   // mark_res[h]: after sub-tiles 2h, 2h+1
 
     // ---- operand DMA.  A k-step is 128 columns: every row slice is one whole 128-byte line, fetched by 8 lanes
     // (64-column slices made every line travel L2 -> L1 twice, once per half).  Piece id -> (row = id >> 3, position
@@ -764,9 +764,14 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
 
     // ------------------------------------------------------------------------------------------------
     // one unit: K loop of `cur` into accC (HAS_CUR) with the epilogue of `prev` out of accP (HAS_PREV)
-    auto tile_body = [&](auto has_cur_t, auto has_prev_t, v16i(&accC)[2][2], v16i(&accP)[2][2], const GaUnit cur,
+    auto tile_body = [&](auto has_cur_t, auto has_prev_t, auto eh_t, v16i(&accC)[2][2], v16i(&accP)[2][2], const GaUnit cur,
                          const GaUnit prev, const GaUnit next, const int round) __attribute__((always_inline)) {
         constexpr bool HAS_CUR = decltype(has_cur_t)::value, HAS_PREV = decltype(has_prev_t)::value;
+        // EH: which half of `prev`'s int16 epilogue this body carries — -1: all four sub-tiles (K = 384, one round per
+        // unit); 0 / 1: sub-tiles 0, 1 / 2, 3 (K > 384: the epilogue is spread over the unit's first two rounds, so only
+        // 16 residual registers are live at a time — with all 32 the K > 384 flavour spilled loop scalars)
+        constexpr int EH = decltype(eh_t)::value;
+        constexpr int KB16 = EH < 0 ? 0 : 4 * EH, NK16 = EH < 0 ? 8 : 4;
 
         // ---- epilogue of `prev`, in pieces small enough to be dealt out between the MFMA groups of a pair.
         // Sub-tile C = (i = C & 1, j = C >> 1).  int8: four quads (requant + pack) and a finish (half-wave exchange +
@@ -859,7 +864,8 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
         };
         auto res_math = [&](auto c_t, int h2, int q) __attribute__((always_inline)) {
             constexpr int C = decltype(c_t)::value;
-            const v4i rs = h2 ? resv[C * 2 + 1] : resv[C * 2];
+            constexpr int RB = (EH < 0 ? C : (C & 1)) * 2;
+            const v4i rs = h2 ? resv[RB + 1] : resv[RB];
             const int t0 = (int)(short)(v16[q] & 0xffff), t1 = v16[q] >> 16;
             const int r0 = (int)(short)(rs[q] & 0xffff), r1 = rs[q] >> 16;
             int o0 = rq_fast(r0, cr) + rq_fast(t0, cm);
@@ -870,9 +876,9 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
         constexpr int S16 = 14;      // first slot of the int16 pieces (their residual lands with the step-0 wait)
         auto chunk16 = [&](auto s_t) __attribute__((always_inline)) {
             constexpr int S = decltype(s_t)::value;
-            if constexpr (S == S16 - 2) cq_quad(0, prev, 0, 0);
-            if constexpr (S >= S16 && S < S16 + 32) {
-                constexpr int k = (S - S16) >> 2, ph = (S - S16) & 3, C = k >> 1, h2 = k & 1, i = C & 1, j = C >> 1;
+            if constexpr (S == S16 - 2) cq_quad(0, prev, KB16 >> 1, 0);
+            if constexpr (S >= S16 && S < S16 + 4 * NK16) {
+                constexpr int k = KB16 + ((S - S16) >> 2), ph = (S - S16) & 3, C = k >> 1, h2 = k & 1, i = C & 1, j = C >> 1;
                 const std::integral_constant<int, C> c_t{};
                 if constexpr (ph == 0) {
                     cq_quad(1, prev, C, h2 + 2);
@@ -881,7 +887,7 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
                     GA_PIN4(oq[0], oq[1], oq[2], oq[3]);
                     pack16(oq, w16[0]);
                     GA_PIN2(w16[0][0], w16[0][1]);
-                    if constexpr (k + 1 < 8) cq_quad(0, prev, (k + 1) >> 1, (k + 1) & 1);
+                    if constexpr (k + 1 < KB16 + NK16) cq_quad(0, prev, (k + 1) >> 1, (k + 1) & 1);
                     rq_asm(c_t, h2 + 2, cqv[1], oq);
                 } else if constexpr (ph == 2) {
                     GA_PIN4(oq[0], oq[1], oq[2], oq[3]);
@@ -913,10 +919,11 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
             const bool ok = grow < p.M && gcol < p.N;
             const unsigned off = ok ? ((unsigned)grow * (unsigned)p.ldc + (unsigned)gcol) * 2 : GA_OOB;
             const __amdgpu_buffer_rsrc_t rs = ga_rsrc(p.residual);
-            resv[C * 2] = ga_bufload16_async(rs, off, 0);
-            resv[C * 2 + 1] = ga_bufload16_async(rs, off, 16);
+            constexpr int RB = (EH < 0 ? C : (C & 1)) * 2;
+            resv[RB] = ga_bufload16_async(rs, off, 0);
+            resv[RB + 1] = ga_bufload16_async(rs, off, 16);
             issued += 2;
-            mark_res[C] = issued;
+            mark_res[EH < 0 ? (C >> 1) : 0] = issued;
         };
 
         // fragments of (k-step KT, 32-column half kk) and the 4 MFMAs that consume them
@@ -980,9 +987,9 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
                     // the next section's fragments, requested behind this section's first MFMA (whose operand wait then
                     // does not cover them) and three MFMAs ahead of their use
                     if (HAS_CUR) frag_load(std::integral_constant<int, KTN>{}, std::integral_constant<int, QN>{}, fa[(G + 1) & 1], fb[(G + 1) & 1]);
-                    if constexpr (RES && HAS_PREV && G < 2) {
-                        res_request(std::integral_constant<int, 2 * G>{}, prev);
-                        res_request(std::integral_constant<int, 2 * G + 1>{}, prev);
+                    if constexpr (RES && HAS_PREV && G < (EH < 0 ? 2 : 1)) {
+                        res_request(std::integral_constant<int, (EH < 0 ? 2 * G : 2 * EH)>{}, prev);
+                        res_request(std::integral_constant<int, (EH < 0 ? 2 * G : 2 * EH) + 1>{}, prev);
                     }
                 }
                 if constexpr (HAS_PREV) {
@@ -1009,7 +1016,8 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
                 // for the next body: the first quad's multipliers; the next unit's bias into the drained accumulators
                 // (harmless before the last round)
                 if (OUT8) cq_quad(0, cur, 0, 0);
-                bias_init(accP, next.cb);
+                // (harmless before the last round; not while sub-tiles 2, 3 of `prev` still wait in accP: EH == 0)
+                if constexpr (EH != 0) bias_init(accP, next.cb);
             }
             if (Q == 2) {
                 // the next step's slices (requested two steps ago), the residual pieces of the next four sections, at
@@ -1017,13 +1025,13 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
                 int n = 1 << 20;
                 if (HAS_CUR) n = issued - mark[(PP + 1) % GA_NK];
                 if (HAS_CUR && PP == 2) n = min(n, issued - mark_cst);
-                if (RES && HAS_PREV && PP < 2) n = min(n, issued - mark_res[2 * PP + 1]);
+                if (RES && HAS_PREV && PP < (EH < 0 ? 2 : 1)) n = min(n, issued - mark_res[PP]);
                 if (G3_TRACE && HAS_CUR) { __builtin_amdgcn_sched_barrier(0); trace(PP, 4); }
-                if (HAS_CUR || (RES && HAS_PREV && PP < 2)) {
+                if (HAS_CUR || (RES && HAS_PREV && PP < (EH < 0 ? 2 : 1))) {
                     if (G3_WAIT_TABLE) ga_wait_vm(n);
                     else ga_wait_vm_fast<MULTI ? 8 : 4, MULTI ? 6 : 2>(n);
                 }
-                if constexpr (RES && HAS_PREV && PP < 2)      // tie the residual registers to the wait
+                if constexpr (RES && HAS_PREV && PP < (EH < 0 ? 2 : 1))      // tie the residual registers to the wait
                     asm volatile("" : "+v"(resv[PP * 4]), "+v"(resv[PP * 4 + 1]), "+v"(resv[PP * 4 + 2]), "+v"(resv[PP * 4 + 3]));
                 if (G3_TRACE && HAS_CUR) trace(PP, 5);
                 if (HAS_CUR) __builtin_amdgcn_s_barrier();
@@ -1084,16 +1092,36 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
     const std::true_type T{};
     const std::false_type F{};
     // round 0 of a unit carries the previous unit's epilogue; rounds 1.. (K > 384) only multiply
-    tile_body(T, F, acc0, acc1, cur, prev, next, 0);
-    if (MULTI) for (int r = 1; r < nrounds; ++r) tile_body(T, F, acc0, acc1, cur, prev, next, r);
-    for (;;) {
-        if (!advance()) { tile_body(F, T, acc1, acc0, cur, prev, next, 0); break; }
-        tile_body(T, T, acc1, acc0, cur, prev, next, 0);
-        if (MULTI) for (int r = 1; r < nrounds; ++r) tile_body(T, F, acc1, acc0, cur, prev, next, r);
-        if (!advance()) { tile_body(F, T, acc0, acc1, cur, prev, next, 0); break; }
-        tile_body(T, T, acc0, acc1, cur, prev, next, 0);
-        if (MULTI) for (int r = 1; r < nrounds; ++r) tile_body(T, F, acc0, acc1, cur, prev, next, r);
+    const std::integral_constant<int, -1> EA{};
+    const std::integral_constant<int, 0> E0{};
+    const std::integral_constant<int, 1> E1{};
+    constexpr bool SPLIT = MULTI && !OUT8;        // int16 epilogue over the unit's first two rounds (K >= 768)
+    // round 0 of a unit carries the previous unit's epilogue (the first two rounds if SPLIT); later rounds only multiply
+#define GA_UNIT(HP, aC, aP)                                                                         \
+    if constexpr (SPLIT) {                                                                          \
+        tile_body(T, HP, E0, aC, aP, cur, prev, next, 0);                                           \
+        tile_body(T, HP, E1, aC, aP, cur, prev, next, 1);                                           \
+        for (int r = 2; r < nrounds; ++r) tile_body(T, F, EA, aC, aP, cur, prev, next, r);          \
+    } else {                                                                                        \
+        tile_body(T, HP, EA, aC, aP, cur, prev, next, 0);                                           \
+        if (MULTI) for (int r = 1; r < nrounds; ++r) tile_body(T, F, EA, aC, aP, cur, prev, next, r); \
     }
+#define GA_DRAIN(aC, aP)                                                                            \
+    if constexpr (SPLIT) {                                                                          \
+        tile_body(F, T, E0, aC, aP, cur, prev, next, 0);                                            \
+        tile_body(F, T, E1, aC, aP, cur, prev, next, 0);                                            \
+    } else {                                                                                        \
+        tile_body(F, T, EA, aC, aP, cur, prev, next, 0);                                            \
+    }
+    GA_UNIT(F, acc0, acc1)
+    for (;;) {
+        if (!advance()) { GA_DRAIN(acc1, acc0) break; }
+        GA_UNIT(T, acc1, acc0)
+        if (!advance()) { GA_DRAIN(acc0, acc1) break; }
+        GA_UNIT(T, acc0, acc1)
+    }
+#undef GA_UNIT
+#undef GA_DRAIN
     if (G3_TRACE && bid == 0) {
         __syncthreads();
         unsigned long long *dst = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(p.dummy) + 1024);

@@ -751,11 +751,13 @@ def test_attention_shiftmax_tables_equal_arithmetic(H, scale):
 
 # ---------------------------------------------------------------- persistent pipelined GEMMs (csrc/ivit_gemm3.h)
 @pytest.mark.parametrize("M,N,K", [(256, 128, 384), (788, 384, 384), (1000, 1152, 384), (513, 1536, 384), (300, 384, 1536),
-                                   (2571, 384, 768), (257, 160, 384), (4099, 256, 1152), (255, 384, 384), (640, 96, 320)])
+                                   (2571, 384, 768), (257, 160, 384), (4099, 256, 1152), (255, 384, 384), (640, 96, 320),
+                                   (1300, 768, 768), (600, 1024, 1536), (257, 544, 1152)])
 def test_planned_linear_epilogues_vs_oracle(H, M, N, K):
     """ivit_linear_*_planned == oracle linear + requant for the 8-bit, 16-bit and 16-bit + residual epilogues.
     K % 384 == 0 shapes with M >= 256 run gemm_as_kernel (A-stationary for K = 384, streaming rounds above), others the
-    launch-per-tile kernels behind the same entry points; ragged M / N exercise the scratch-redirected stores."""
+    launch-per-tile kernels behind the same entry points (and the residual flavour below N = 512); ragged M / N exercise
+    the range-checked buffer stores; K >= 768 with N >= 512 the int16 epilogue spread over two rounds."""
     from oracle import oracle as orc
     rng = np.random.default_rng(M + 3 * N + 7 * K)
     x = rng.integers(-128, 128, (M, K), dtype=np.int8)
