@@ -497,6 +497,12 @@ __global__ __launch_bounds__(G3Cfg<ASTAT>::NT, 2) void gemm_ps_kernel(GemmArgs p
 //   * 256 registers hold two accumulator sets (128), double-buffered fragments (32), the residual pieces (32, int16 +
 //     residual flavour only) and little else: per-lane addresses are recomputed from an opaque copy of the thread id
 //     at each use instead of living across the unit loop.
+//   * K > 384, int16 epilogues: the previous unit's epilogue is spread over the unit's first TWO rounds (16 residual
+//     registers live instead of 32) — with all 32 the compiler kept loop scalars in VGPRs and spilled them, and every
+//     spill reload carries an s_waitcnt vmcnt(0) that drains the DMA ring;
+//   * the counted wait is `s_waitcnt vmcnt(C)` with C = the smallest count the steady state produces (4, or 8 with A
+//     streaming) whenever the exact count n >= C — only stricter, never wrong — and falls back to smaller immediates at
+//     a workgroup's first and last units (ga_wait_vm_fast; the exact jump table stays behind G3_WAIT_TABLE).
 // Where it stands (fc1, 50432 x 1536 x 384): 45.6 us = 1.30 POP/s.  The matrix pipe sustains 47 cycles per MFMA on
 // random int8 data and the fp64 requant costs ~19 SIMD-cycles per 64 outputs that do NOT hide behind MFMAs of the
 // other wave (tools/ubench/overlap.hip: 46.6 cycles per MFMA alone, 72 with this kernel's 1.33 outputs per MFMA):
