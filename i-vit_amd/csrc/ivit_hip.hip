@@ -1,6 +1,7 @@
 // ivit_hip.hip — C-ABI (include/ivit.h) over the gfx950 kernels.
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -415,7 +416,8 @@ static inline bool use_gemm3(const ivit_linear_plan_s *pl, const GemmArgs &a, in
     static const int on = env_int("IVIT_GEMM3", 7);
     // the residual flavour on a narrow output (N = 384: three channel tiles per 256-token panel, 77 % balance, and its
     // 32 resident residual registers) measured no better in-model than the launch-per-tile kernel: N >= 512 only
-    if (epi_bit == 4 && a.N < 512) return false;
+    static const int res_min_n = env_int("IVIT_GEMM3_RES_MIN_N", 512);
+    if (epi_bit == 4 && a.N < res_min_n) return false;
     return (on & epi_bit) && pl->pipelined_ok && (a.K % 64) == 0 && a.K >= 320 && (a.N % 16) == 0 && (a.ldc % 16) == 0 &&
            (a.lda % 16) == 0 && (a.ldb % 16) == 0 && a.M >= 128;
 }
@@ -430,10 +432,14 @@ static int launch_gemm3(ivit_handle h, const ivit_linear_plan_s *pl, GemmArgs &a
     static const int dbg3 = env_int("IVIT_GEMM3_DBG", 0), astat_on = env_int("IVIT_GEMM3_ASTAT", 1);
     a.dbg = dbg3;
     const bool fma = force_fma >= 0 ? (force_fma != 0 && pl->single_fma_ok) : (pl->single_fma_ok != 0);
-    // A-stationary kernel: K == 384; the qkv scatter additionally needs whole units inside one of q / k / v and
-    // whole 32-channel groups inside one head
+    // gemm_as_kernel: K = n * 384; the qkv scatter additionally needs whole units inside one of q / k / v and whole
+    // 32-channel groups inside one head.  Its operand offsets are 32-bit and its epilogue goes through buffer
+    // resources (offsets < 2^31, out-of-range lanes parked at 0x80000000): larger tensors take the 64-bit kernels.
+    const long long out_bytes = (EPI == EPI_QKV) ? std::max((long long)a.M * a.D, (long long)(a.M / (a.T > 0 ? a.T : 1) + 1) * a.D * a.ldv)
+                                                 : (long long)a.M * a.ldc * ((EPI == EPI_RQ8_CH) ? 1 : 2);
     const bool astat = astat_on && (a.K % (GA_BK * GA_NK)) == 0 && a.M >= 256 && (a.N % 32) == 0 &&
                        (long long)a.M * a.lda < (1LL << 32) && (long long)a.N * a.ldb < (1LL << 32) &&
+                       out_bytes < (1LL << 31) &&
                        (EPI != EPI_QKV || ((a.D % 128) == 0 && (a.dh % 32) == 0));
     if (astat) {
         const long long nunits = (long long)((a.M + 255) / 256) * a.tiles_n;
