@@ -445,6 +445,13 @@ static int launch_gemm3(ivit_handle h, const ivit_linear_plan_s *pl, GemmArgs &a
         const long long nunits = (long long)((a.M + 255) / 256) * a.tiles_n;
         long long grid = h->num_cu;
         if (grid > nunits) grid = nunits;
+        // experiment switch: the fewest workgroups with the same makespan (units per workgroup = ceil(nunits / CUs)), so
+        // that the CUs left over run the other batch slices' kernels.  Measured neutral (3.58-3.61 ms either way): off.
+        static const int trim = env_int("IVIT_GEMM3_TRIM_GRID", 0);
+        if (trim) {
+            const long long upw = (nunits + grid - 1) / grid;
+            grid = (nunits + upw - 1) / upw;
+        }
         const dim3 g((unsigned)grid);
         if (a.K == GA_BK * GA_NK) {
             if (fma) gemm_as_kernel<EPI, false, true><<<g, 512, 0, h->stream>>>(a);
