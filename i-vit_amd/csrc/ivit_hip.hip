@@ -720,8 +720,9 @@ int ivit_layernorm_requant(ivit_handle h, const int16_t *x, int64_t rows, int C,
         static const int ln_old = env_int("IVIT_LN_OLD", 0), force_riter = env_int("IVIT_LN_RITER", 0);
         if (lds16 <= 150 * 1024 && !ln_old) {
             // row groups per block: up to LN_RITER (amortises the constant staging), fewer when the launch would
-            // otherwise leave CUs idle (>= 3 blocks per CU wanted)
-            long long riter = rows / (16LL * 3 * h->num_cu);
+            // otherwise be too coarse: with 3.08 blocks per CU (DeiT-S b256, riter 4) the 20 CUs that get a fourth block
+            // set the kernel's time; >= 6 blocks per CU wanted (measured: 0.76 -> 0.70 ms per forward)
+            long long riter = rows / (16LL * 6 * h->num_cu);
             riter = riter < 1 ? 1 : (riter > LN_RITER ? LN_RITER : riter);
             if (force_riter > 0) riter = force_riter;
             const long long per_block = 16 * riter;
