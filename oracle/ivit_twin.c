@@ -1,0 +1,396 @@
+/*
+ * ivit_twin.c — CPU twin of the C-ABI (SURVEY.md §8b "a CPU twin of every entry point (same signatures, host
+ * pointers) used as the portable oracle").  TEST INFRASTRUCTURE ONLY, like the rest of oracle/: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it; the product path never does.
+ *
+ * Every function ivit_cpu_X has the parameter list of ivit_X in include/ivit.h (tests/test_twin.py compares the two
+ * headers textually) and the same result on host buffers.  The handle argument is ignored (pass NULL).  The bodies are
+ * compositions of the restated operators of ivit_oracle.c (each of which cites the reference lines it follows), in the
+ * order the reference's modules chain them; the reference citation of an entry point is the one in include/ivit.h.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "ivit_twin.h"
+
+/* ---- restated operators (ivit_oracle.c) */
+void ivit_ref_quantize_f32(const float *x, float scale, int bits, int32_t *q, int64_t n);
+void ivit_ref_linear_i8(const int8_t *x, const int8_t *w, const int32_t *bias, int32_t *acc, int64_t M, int64_t N,
+                        int64_t K);
+void ivit_ref_bmm_av(const uint16_t *P, int64_t ldp, const int8_t *V, int32_t *C, int64_t nb, int64_t M, int64_t T,
+                     int64_t D);
+void ivit_ref_requant_f32(const float *z, const ivit_dyadic *dy, int64_t nch, const float *z_id,
+                          const ivit_dyadic *dy_id, int bits, int32_t *out, int64_t rows, int64_t C);
+void ivit_ref_requant_i32(const int32_t *z, const ivit_dyadic *dy, int64_t nch, const int32_t *z_id,
+                          const ivit_dyadic *dy_id, int bits, int32_t *out, int64_t rows, int64_t C);
+void ivit_ref_shiftmax(const int8_t *x, int64_t rows, int64_t n, int64_t ld_in, float s, int out_bits, uint16_t *out,
+                       int64_t ld_out);
+void ivit_ref_shiftgelu(const int8_t *x, int64_t rows, int64_t C, float s, int16_t *out);
+void ivit_ref_layernorm(const int16_t *x, int64_t rows, int64_t C, float s, const float *bias_int, const float *sc,
+                        float *z);
+void ivit_ref_im2col_patch(const int8_t *img, int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t P, int8_t *out);
+
+#define TW_OK 0
+#define TW_INVALID 1
+#define TW_REQ(c) do { if (!(c)) return TW_INVALID; } while (0)
+
+static void *xmalloc(size_t n) { return malloc(n ? n : 1); }
+
+/* int32 -> narrower integer store of a requantised tensor (the values are already clamped to `bits`) */
+static void store_bits(const int32_t *v, int bits, void *out, int64_t n) {
+    if (bits == 8) for (int64_t i = 0; i < n; ++i) ((int8_t *)out)[i] = (int8_t)v[i];
+    else if (bits == 16) for (int64_t i = 0; i < n; ++i) ((int16_t *)out)[i] = (int16_t)v[i];
+    else memcpy(out, v, (size_t)n * 4);
+}
+
+int ivit_cpu_quantize_input_f32(ivit_handle h, const float *x, float scale, int8_t *q, int64_t n) {
+    (void)h;
+    TW_REQ(x && q && n > 0 && scale > 0.f);
+    int32_t *t = (int32_t *)xmalloc((size_t)n * 4);
+    ivit_ref_quantize_f32(x, scale, 8, t, n);
+    store_bits(t, 8, q, n);
+    free(t);
+    return TW_OK;
+}
+
+int ivit_cpu_linear_i8(ivit_handle h, const int8_t *x, const int8_t *w, const int32_t *bias, int32_t *acc, int M,
+                       int N, int K) {
+    (void)h;
+    TW_REQ(x && w && acc && M > 0 && N > 0 && K > 0);
+    ivit_ref_linear_i8(x, w, bias, acc, M, N, K);
+    return TW_OK;
+}
+
+int ivit_cpu_linear_i8_requant(ivit_handle h, const int8_t *x, const int8_t *w, const int32_t *bias,
+                               const ivit_dyadic *dy_ch, int bits, void *out, int M, int N, int K) {
+    (void)h;
+    TW_REQ(x && w && dy_ch && out && (bits == 8 || bits == 16) && M > 0 && N > 0 && K > 0);
+    int32_t *acc = (int32_t *)xmalloc((size_t)M * N * 4);
+    ivit_ref_linear_i8(x, w, bias, acc, M, N, K);
+    ivit_ref_requant_i32(acc, dy_ch, N, NULL, NULL, bits, acc, M, N);
+    store_bits(acc, bits, out, (int64_t)M * N);
+    free(acc);
+    return TW_OK;
+}
+
+/* t = clamp16(rq(acc, dy_ch[j])); out = clamp16(rq(t, dy_main) + rq(residual, dy_res)) */
+static void residual_tail(int32_t *t, ivit_dyadic dy_main, ivit_dyadic dy_res, const int16_t *residual, int16_t *out,
+                          int64_t M, int64_t N) {
+    int32_t *r32 = (int32_t *)xmalloc((size_t)M * N * 4);
+    for (int64_t i = 0; i < M * N; ++i) r32[i] = residual[i];
+    ivit_ref_requant_i32(t, &dy_main, 1, r32, &dy_res, 16, t, M, N);
+    store_bits(t, 16, out, M * N);
+    free(r32);
+}
+
+int ivit_cpu_linear_i8_requant_residual(ivit_handle h, const int8_t *x, const int8_t *w, const int32_t *bias,
+                                        const ivit_dyadic *dy_ch, ivit_dyadic dy_main, ivit_dyadic dy_res,
+                                        const int16_t *residual, int16_t *out, int M, int N, int K) {
+    (void)h;
+    TW_REQ(x && w && dy_ch && residual && out && M > 0 && N > 0 && K > 0);
+    int32_t *acc = (int32_t *)xmalloc((size_t)M * N * 4);
+    ivit_ref_linear_i8(x, w, bias, acc, M, N, K);
+    ivit_ref_requant_i32(acc, dy_ch, N, NULL, NULL, 16, acc, M, N);
+    residual_tail(acc, dy_main, dy_res, residual, out, M, N);
+    free(acc);
+    return TW_OK;
+}
+
+int ivit_cpu_linear_i8_qkv(ivit_handle h, const int8_t *x, const int8_t *w, const int32_t *bias,
+                           const ivit_dyadic *dy_ch, int8_t *q, int8_t *k, int8_t *vt, int B, int T, int H, int dh,
+                           int ldv) {
+    (void)h;
+    TW_REQ(x && w && dy_ch && q && k && vt && B > 0 && T > 0 && H > 0 && dh > 0 && ldv >= T);
+    const int64_t D = (int64_t)H * dh, M = (int64_t)B * T, N = 3 * D;
+    int32_t *acc = (int32_t *)xmalloc((size_t)M * N * 4);
+    ivit_ref_linear_i8(x, w, bias, acc, M, N, D);
+    ivit_ref_requant_i32(acc, dy_ch, N, NULL, NULL, 8, acc, M, N);
+    /* vit_quant.py:63-69: [B, T, 3, H, dh] -> q, k [B, H, T, dh]; v transposed [B, H, dh, ldv] (pad columns untouched) */
+    for (int64_t b = 0; b < B; ++b)
+        for (int64_t t = 0; t < T; ++t)
+            for (int64_t hh = 0; hh < H; ++hh)
+                for (int64_t d = 0; d < dh; ++d) {
+                    const int32_t *row = acc + (b * T + t) * N;
+                    const int64_t bh = b * H + hh;
+                    q[(bh * T + t) * dh + d] = (int8_t)row[hh * dh + d];
+                    k[(bh * T + t) * dh + d] = (int8_t)row[D + hh * dh + d];
+                    vt[(bh * dh + d) * ldv + t] = (int8_t)row[2 * D + hh * dh + d];
+                }
+    free(acc);
+    return TW_OK;
+}
+
+/* ---- plans: the twin keeps the pointers; the planned entry points are the unplanned ones */
+struct ivit_cpu_plan_s { const int8_t *w; const int32_t *bias; const ivit_dyadic *dy; int N, K; };
+
+int ivit_cpu_linear_plan_create(ivit_handle h, const int8_t *w, const int32_t *bias, const ivit_dyadic *dy_ch, int N,
+                                int K, ivit_linear_plan *out) {
+    (void)h;
+    TW_REQ(w && dy_ch && out && N > 0 && K > 0);
+    struct ivit_cpu_plan_s *p = (struct ivit_cpu_plan_s *)xmalloc(sizeof(*p));
+    p->w = w; p->bias = bias; p->dy = dy_ch; p->N = N; p->K = K;
+    *out = (ivit_linear_plan)p;
+    return TW_OK;
+}
+int ivit_cpu_linear_plan_destroy(ivit_linear_plan p) { free(p); return TW_OK; }
+int ivit_cpu_linear_plan_query(ivit_linear_plan p, int *pipelined_ok, int *single_fma_ok) {
+    TW_REQ(p);
+    if (pipelined_ok) *pipelined_ok = 1;
+    if (single_fma_ok) *single_fma_ok = 1;
+    return TW_OK;
+}
+int ivit_cpu_linear_i8_requant_planned(ivit_handle h, ivit_linear_plan p, const int8_t *x, int bits, void *out, int M) {
+    const struct ivit_cpu_plan_s *pl = (const struct ivit_cpu_plan_s *)p;
+    TW_REQ(pl);
+    return ivit_cpu_linear_i8_requant(h, x, pl->w, pl->bias, pl->dy, bits, out, M, pl->N, pl->K);
+}
+int ivit_cpu_linear_i8_requant_residual_planned(ivit_handle h, ivit_linear_plan p, const int8_t *x, ivit_dyadic dy_main,
+                                                ivit_dyadic dy_res, const int16_t *residual, int16_t *out, int M) {
+    const struct ivit_cpu_plan_s *pl = (const struct ivit_cpu_plan_s *)p;
+    TW_REQ(pl);
+    return ivit_cpu_linear_i8_requant_residual(h, x, pl->w, pl->bias, pl->dy, dy_main, dy_res, residual, out, M, pl->N,
+                                               pl->K);
+}
+int ivit_cpu_linear_i8_qkv_planned(ivit_handle h, ivit_linear_plan p, const int8_t *x, int8_t *q, int8_t *k, int8_t *vt,
+                                   int B, int T, int H, int dh, int ldv) {
+    const struct ivit_cpu_plan_s *pl = (const struct ivit_cpu_plan_s *)p;
+    TW_REQ(pl && pl->N == 3 * H * dh && pl->K == H * dh);
+    return ivit_cpu_linear_i8_qkv(h, x, pl->w, pl->bias, pl->dy, q, k, vt, B, T, H, dh, ldv);
+}
+
+/* ---- a2 */
+int ivit_cpu_bmm_nt_i8(ivit_handle h, const int8_t *A, const int8_t *B, int32_t *C, int nb, int M, int N, int K, int lda,
+                       int ldb, int ldc, int64_t strideA, int64_t strideB, int64_t strideC) {
+    (void)h;
+    TW_REQ(A && B && C && nb > 0 && M > 0 && N > 0 && K > 0);
+    for (int64_t b = 0; b < nb; ++b)
+        for (int64_t i = 0; i < M; ++i)
+            for (int64_t j = 0; j < N; ++j) {
+                const int8_t *a = A + b * strideA + i * lda, *bb = B + b * strideB + j * ldb;
+                int32_t s = 0;
+                for (int64_t kk = 0; kk < K; ++kk) s += (int32_t)a[kk] * (int32_t)bb[kk];
+                C[b * strideC + i * ldc + j] = s;
+            }
+    return TW_OK;
+}
+
+int ivit_cpu_bmm_nt_u16i8(ivit_handle h, const uint16_t *A, const int8_t *B, int32_t *C, int nb, int M, int N, int K,
+                          int lda, int ldb, int ldc, int64_t strideA, int64_t strideB, int64_t strideC) {
+    (void)h;
+    TW_REQ(A && B && C && nb > 0 && M > 0 && N > 0 && K > 0);
+    for (int64_t b = 0; b < nb; ++b)
+        for (int64_t i = 0; i < M; ++i)
+            for (int64_t j = 0; j < N; ++j) {
+                const uint16_t *a = A + b * strideA + i * lda;
+                const int8_t *bb = B + b * strideB + j * ldb;
+                int32_t s = 0;
+                for (int64_t kk = 0; kk < K; ++kk) s += (int32_t)a[kk] * (int32_t)bb[kk];
+                C[b * strideC + i * ldc + j] = s;
+            }
+    return TW_OK;
+}
+
+int ivit_cpu_attn_qk_requant(ivit_handle h, const int8_t *q, const int8_t *k, ivit_dyadic dy, int8_t *scores8, int BH,
+                             int T, int dh, int lds) {
+    TW_REQ(q && k && scores8 && BH > 0 && T > 0 && dh > 0 && lds >= T);
+    int32_t *acc = (int32_t *)xmalloc((size_t)BH * T * T * 4);
+    ivit_cpu_bmm_nt_i8(h, q, k, acc, BH, T, T, dh, dh, dh, T, (int64_t)T * dh, (int64_t)T * dh, (int64_t)T * T);
+    ivit_ref_requant_i32(acc, &dy, 1, NULL, NULL, 8, acc, (int64_t)BH * T, T);
+    for (int64_t r = 0; r < (int64_t)BH * T; ++r)
+        for (int64_t j = 0; j < T; ++j) scores8[r * lds + j] = (int8_t)acc[r * T + j];
+    free(acc);
+    return TW_OK;
+}
+
+int ivit_cpu_attn_pv_requant(ivit_handle h, const uint16_t *p, const int8_t *vt, ivit_dyadic dy, int8_t *ctx8, int B,
+                             int H, int T, int dh, int ldp, int ldv) {
+    TW_REQ(p && vt && ctx8 && B > 0 && H > 0 && T > 0 && dh > 0 && ldp >= T && ldv >= T);
+    const int64_t BH = (int64_t)B * H;
+    int32_t *acc = (int32_t *)xmalloc((size_t)BH * T * dh * 4);
+    ivit_cpu_bmm_nt_u16i8(h, p, vt, acc, (int)BH, T, dh, T, ldp, ldv, dh, (int64_t)T * ldp, (int64_t)dh * ldv,
+                          (int64_t)T * dh);
+    ivit_ref_requant_i32(acc, &dy, 1, NULL, NULL, 8, acc, BH * T, dh);
+    /* heads merged: x.transpose(1, 2).reshape(B, N, C)  (vit_quant.py:81) */
+    for (int64_t b = 0; b < B; ++b)
+        for (int64_t hh = 0; hh < H; ++hh)
+            for (int64_t t = 0; t < T; ++t)
+                for (int64_t d = 0; d < dh; ++d)
+                    ctx8[(b * T + t) * H * dh + hh * dh + d] = (int8_t)acc[((b * H + hh) * T + t) * dh + d];
+    free(acc);
+    return TW_OK;
+}
+
+int ivit_cpu_attention_fused(ivit_handle h, const int8_t *q, const int8_t *k, const int8_t *vt, ivit_dyadic dy_qk,
+                             float s_softmax, ivit_dyadic dy_pv, int8_t *ctx8, int B, int H, int T, int dh, int ldv) {
+    TW_REQ(q && k && vt && ctx8 && B > 0 && H > 0 && T > 0 && dh > 0 && ldv >= T && s_softmax > 0.f);
+    const int64_t BH = (int64_t)B * H;
+    int8_t *s8 = (int8_t *)xmalloc((size_t)BH * T * T);
+    uint16_t *p16 = (uint16_t *)xmalloc((size_t)BH * T * T * 2);
+    int rc = ivit_cpu_attn_qk_requant(h, q, k, dy_qk, s8, (int)BH, T, dh, T);
+    if (rc == TW_OK) {
+        ivit_ref_shiftmax(s8, BH * T, T, T, s_softmax, 16, p16, T);
+        rc = ivit_cpu_attn_pv_requant(h, p16, vt, dy_pv, ctx8, B, H, T, dh, T, ldv);
+    }
+    free(s8);
+    free(p16);
+    return rc;
+}
+
+/* the table form computes the same integers (the tables are checked exhaustively against the arithmetic when built) */
+int ivit_cpu_attention_fused_lut(ivit_handle h, const int8_t *q, const int8_t *k, const int8_t *vt, ivit_dyadic dy_qk,
+                                 float s_softmax, const uint16_t *exp_aq, const float *exp_t, const uint8_t *exp_cls,
+                                 int nclass, int t_count, int dmin, ivit_dyadic dy_pv, int8_t *ctx8, int B, int H, int T,
+                                 int dh, int ldv) {
+    (void)exp_aq; (void)exp_t; (void)exp_cls; (void)nclass; (void)t_count; (void)dmin;
+    return ivit_cpu_attention_fused(h, q, k, vt, dy_qk, s_softmax, dy_pv, ctx8, B, H, T, dh, ldv);
+}
+
+/* ---- a3 */
+int ivit_cpu_requant_i32(ivit_handle h, const int32_t *z, const ivit_dyadic *dy, int nch, const int32_t *z_id,
+                         const ivit_dyadic *dy_id, int bits, void *out, int64_t rows, int C) {
+    (void)h;
+    TW_REQ(z && dy && out && (nch == 1 || nch == C) && (bits == 8 || bits == 16 || bits == 32) && rows > 0 && C > 0 &&
+           (!z_id || dy_id));
+    int32_t *t = (int32_t *)xmalloc((size_t)rows * C * 4);
+    ivit_ref_requant_i32(z, dy, nch, z_id, dy_id, bits, t, rows, C);
+    store_bits(t, bits, out, rows * C);
+    free(t);
+    return TW_OK;
+}
+int ivit_cpu_requant_i16(ivit_handle h, const int16_t *z, const ivit_dyadic *dy, int nch, const int32_t *z_id,
+                         const ivit_dyadic *dy_id, int bits, void *out, int64_t rows, int C) {
+    TW_REQ(z && rows > 0 && C > 0);
+    int32_t *z32 = (int32_t *)xmalloc((size_t)rows * C * 4);
+    for (int64_t i = 0; i < rows * C; ++i) z32[i] = z[i];
+    const int rc = ivit_cpu_requant_i32(h, z32, dy, nch, z_id, dy_id, bits, out, rows, C);
+    free(z32);
+    return rc;
+}
+int ivit_cpu_requant_f32(ivit_handle h, const float *z, const ivit_dyadic *dy, int nch, const int32_t *z_id,
+                         const ivit_dyadic *dy_id, int bits, void *out, int64_t rows, int C) {
+    (void)h;
+    TW_REQ(z && dy && out && (nch == 1 || nch == C) && (bits == 8 || bits == 16 || bits == 32) && rows > 0 && C > 0 &&
+           (!z_id || dy_id));
+    int32_t *t = (int32_t *)xmalloc((size_t)rows * C * 4);
+    float *zid = NULL;
+    if (z_id) {
+        zid = (float *)xmalloc((size_t)rows * C * 4);
+        for (int64_t i = 0; i < rows * C; ++i) zid[i] = (float)z_id[i];     /* exact: |identity| < 2^24 on this path */
+    }
+    ivit_ref_requant_f32(z, dy, nch, zid, dy_id, bits, t, rows, C);
+    store_bits(t, bits, out, rows * C);
+    free(zid);
+    free(t);
+    return TW_OK;
+}
+
+/* ---- a5, a6 */
+int ivit_cpu_shiftmax(ivit_handle h, const int8_t *x, int64_t rows, int n, int ld_in, float scale, int out_bits,
+                      uint16_t *out, int ld_out) {
+    (void)h;
+    TW_REQ(x && out && rows > 0 && n > 0 && ld_in >= n && ld_out >= n && scale > 0.f && (out_bits == 8 || out_bits == 16));
+    ivit_ref_shiftmax(x, rows, n, ld_in, scale, out_bits, out, ld_out);
+    return TW_OK;
+}
+int ivit_cpu_shiftgelu(ivit_handle h, const int8_t *x, int64_t rows, int C, float scale, int16_t *out16) {
+    (void)h;
+    TW_REQ(x && out16 && rows > 0 && C > 0 && scale > 0.f);
+    ivit_ref_shiftgelu(x, rows, C, scale, out16);
+    return TW_OK;
+}
+int ivit_cpu_shiftgelu_requant(ivit_handle h, const int8_t *x, int64_t rows, int C, float scale, ivit_dyadic dy,
+                               int8_t *out8) {
+    TW_REQ(x && out8 && rows > 0 && C > 0 && scale > 0.f);
+    int16_t *g = (int16_t *)xmalloc((size_t)rows * C * 2);
+    ivit_ref_shiftgelu(x, rows, C, scale, g);
+    const int rc = ivit_cpu_requant_i16(h, g, &dy, 1, NULL, NULL, 8, out8, rows, C);
+    free(g);
+    return rc;
+}
+/* table[(qmax + 128) * 256 + (Q + 128)] for Q <= qmax (a row's maximum bounds its elements; the other half of the
+ * table is never indexed and left 0): the two-element row {Q, qmax} has the same maximum, hence the same result */
+int ivit_cpu_shiftgelu_build_table(ivit_handle h, float scale, ivit_dyadic dy, int8_t *table) {
+    TW_REQ(table && scale > 0.f);
+    memset(table, 0, 65536);
+    for (int qmax = -128; qmax < 128; ++qmax)
+        for (int Q = -128; Q <= qmax; ++Q) {
+            const int8_t row[2] = {(int8_t)Q, (int8_t)qmax};
+            int8_t o[2];
+            const int rc = ivit_cpu_shiftgelu_requant(h, row, 1, 2, scale, dy, o);
+            if (rc) return rc;
+            table[(qmax + 128) * 256 + (Q + 128)] = o[0];
+        }
+    return TW_OK;
+}
+int ivit_cpu_shiftgelu_requant_lut(ivit_handle h, const int8_t *x, int64_t rows, int C, const int8_t *table,
+                                   int8_t *out8) {
+    (void)h;
+    TW_REQ(x && table && out8 && rows > 0 && C > 0);
+    for (int64_t r = 0; r < rows; ++r) {
+        int qmax = -128;
+        for (int c = 0; c < C; ++c) qmax = x[r * C + c] > qmax ? x[r * C + c] : qmax;
+        for (int c = 0; c < C; ++c) out8[r * C + c] = table[(qmax + 128) * 256 + (x[r * C + c] + 128)];
+    }
+    return TW_OK;
+}
+
+/* ---- a7 */
+int ivit_cpu_layernorm(ivit_handle h, const int16_t *x, int64_t rows, int C, float scale, const float *bias_int,
+                       const float *sc, float *z) {
+    (void)h;
+    TW_REQ(x && bias_int && sc && z && rows > 0 && C > 0 && scale > 0.f);
+    ivit_ref_layernorm(x, rows, C, scale, bias_int, sc, z);
+    return TW_OK;
+}
+int ivit_cpu_layernorm_requant(ivit_handle h, const int16_t *x, int64_t rows, int C, int64_t row_stride, float scale,
+                               const float *bias_int, const float *sc, const ivit_dyadic *dy_ch, int8_t *out8) {
+    TW_REQ(x && bias_int && sc && dy_ch && out8 && rows > 0 && C > 0 && row_stride >= C && scale > 0.f);
+    int16_t *xc = (int16_t *)xmalloc((size_t)rows * C * 2);
+    float *z = (float *)xmalloc((size_t)rows * C * 4);
+    for (int64_t r = 0; r < rows; ++r) memcpy(xc + r * C, x + r * row_stride, (size_t)C * 2);
+    ivit_ref_layernorm(xc, rows, C, scale, bias_int, sc, z);
+    const int rc = ivit_cpu_requant_f32(h, z, dy_ch, C, NULL, NULL, 8, out8, rows, C);
+    free(z);
+    free(xc);
+    return rc;
+}
+
+/* ---- a8 */
+int ivit_cpu_im2col_patch(ivit_handle h, const int8_t *img, int B, int Cin, int H, int W, int P, int8_t *rows) {
+    (void)h;
+    TW_REQ(img && rows && B > 0 && Cin > 0 && P > 0 && H % P == 0 && W % P == 0);
+    ivit_ref_im2col_patch(img, B, Cin, H, W, P, rows);
+    return TW_OK;
+}
+int ivit_cpu_embed_finish(ivit_handle h, const int16_t *patch16, const int32_t *z_cls, const int16_t *pos,
+                          ivit_dyadic dy_x, ivit_dyadic dy_pos, int16_t *x16, int B, int T, int D) {
+    (void)h;
+    TW_REQ(patch16 && z_cls && pos && x16 && B > 0 && T > 1 && D > 0);
+    int32_t *z = (int32_t *)xmalloc((size_t)T * D * 4), *pz = (int32_t *)xmalloc((size_t)T * D * 4);
+    for (int64_t i = 0; i < (int64_t)T * D; ++i) pz[i] = pos[i];
+    for (int64_t b = 0; b < B; ++b) {
+        for (int d = 0; d < D; ++d) z[d] = z_cls[d];
+        for (int64_t i = 0; i < (int64_t)(T - 1) * D; ++i) z[D + i] = patch16[b * (int64_t)(T - 1) * D + i];
+        ivit_ref_requant_i32(z, &dy_x, 1, pz, &dy_pos, 16, z, T, D);
+        store_bits(z, 16, x16 + b * (int64_t)T * D, (int64_t)T * D);
+    }
+    free(z);
+    free(pz);
+    return TW_OK;
+}
+
+/* ---- a9, the fused form of the narrow Swin stage */
+int ivit_cpu_mlp_fused(ivit_handle h, const int8_t *x, const int8_t *w1, const int32_t *b1, const ivit_dyadic *dy1,
+                       const int8_t *gelu_table, const int8_t *w2, const int32_t *b2, const ivit_dyadic *dy2,
+                       ivit_dyadic dy_main, ivit_dyadic dy_res, const int16_t *residual, int16_t *out, int64_t M, int C,
+                       int hidden) {
+    TW_REQ(x && w1 && dy1 && gelu_table && w2 && dy2 && residual && out && M > 0 && C > 0 && hidden > 0);
+    int8_t *h8 = (int8_t *)xmalloc((size_t)M * hidden), *g8 = (int8_t *)xmalloc((size_t)M * hidden);
+    int rc = ivit_cpu_linear_i8_requant(h, x, w1, b1, dy1, 8, h8, (int)M, hidden, C);
+    if (rc == TW_OK) rc = ivit_cpu_shiftgelu_requant_lut(h, h8, M, hidden, gelu_table, g8);
+    if (rc == TW_OK) rc = ivit_cpu_linear_i8_requant_residual(h, g8, w2, b2, dy2, dy_main, dy_res, residual, out, (int)M, C, hidden);
+    free(h8);
+    free(g8);
+    return rc;
+}

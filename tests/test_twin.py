@@ -1,0 +1,286 @@
+"""CPU twin of the C-ABI (oracle/ivit_twin.c): ivit_cpu_X takes the parameter list of ivit_X with host
+pointers.  CPU part: the generated header is current, every twin symbol is exported, the twin agrees with the golden
+fixtures / the oracle's Python-level chaining.  GPU part: ONE argument list per entry point, executed through the HIP
+library (device pointers) and through the twin (host pointers) with the same ctypes signature — results must be equal
+bit for bit."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+
+import ivit_amd as iv
+from ivit_amd import _lib
+
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import gen_twin_header  # noqa: E402
+
+_P = ctypes.c_void_p
+
+
+@pytest.fixture(scope="module")
+def twin():
+    from oracle import oracle as orc
+    lib = ctypes.CDLL(orc.build())
+    for name in gen_twin_header.TWIN:
+        fn = getattr(lib, "ivit_cpu_" + name)           # AttributeError = a declared twin is not exported
+        fn.argtypes = _sig(name)                        # the C-ABI's own ctypes signature, unchanged
+        fn.restype = ctypes.c_int
+    return lib
+
+
+# the two plan calls without a handle argument are declared outside _lib.SIGNATURES (which prepends nothing, but whose
+# Handle.call wrapper does): same argtypes as _lib.load() sets
+_EXTRA = {"linear_plan_destroy": [_P], "linear_plan_query": [_P, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]}
+
+
+def _sig(name):
+    return _EXTRA.get(name) or _lib.SIGNATURES["ivit_" + name]
+
+
+def hp(a):
+    return a.ctypes.data_as(_P)
+
+
+def dyv(d):
+    return _lib.Dyadic(float(d[0, 0]), float(d[0, 1]))
+
+
+def test_twin_header_is_generated_from_the_c_abi():
+    """oracle/ivit_twin.h == tools/gen_twin_header.py(include/ivit.h): same parameter lists by construction; ivit_twin.c
+    includes it, so a drifting definition does not compile"""
+    assert open(os.path.join(ROOT, "oracle", "ivit_twin.h")).read() == gen_twin_header.render()
+    assert set("ivit_" + n for n in gen_twin_header.TWIN) <= set(_lib.SIGNATURES) | set("ivit_" + n for n in _EXTRA)
+
+
+def test_twin_exports_every_declared_symbol(twin):
+    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "oracle", "libivit_oracle.so")],
+                         capture_output=True, text=True, check=True).stdout
+    for name in gen_twin_header.TWIN:
+        assert f" T ivit_cpu_{name}\n" in out, name
+
+
+def test_twin_operators_match_golden(twin):
+    """the twin's single-operator entry points on the reference's own captured tensors (tests/golden/ops.npz)"""
+    g = load_golden("ops.npz")
+    for i in range(int(g["ln/n"])):
+        x = np.ascontiguousarray(g[f"ln/{i}/x"])
+        rows, C = x.shape
+        bias_int, sc = iv.freeze.layernorm_constants(g[f"ln/{i}/w"], g[f"ln/{i}/b"])
+        z = np.empty((rows, C), np.float32)
+        assert twin.ivit_cpu_layernorm(None, hp(x), rows, C, float(g[f"ln/{i}/s"]), hp(bias_int), hp(sc), hp(z)) == 0
+        assert np.array_equal(z, g[f"ln/{i}/z"]), i
+        d = iv.freeze.dyadic(sc, g[f"ln/{i}/s_out"])
+        o8 = np.empty((rows, C), np.int8)
+        assert twin.ivit_cpu_layernorm_requant(None, hp(x), rows, C, C, float(g[f"ln/{i}/s"]), hp(bias_int), hp(sc),
+                                               hp(d), hp(o8)) == 0
+        assert np.array_equal(o8, g[f"ln/{i}/out8"]), i
+    for i in range(int(g["requant/n"])):
+        z = np.ascontiguousarray(g[f"requant/{i}/z"])
+        rows, C = z.shape
+        bits = int(g[f"requant/{i}/bits"])
+        d = iv.freeze.dyadic(g[f"requant/{i}/s_pre"], g[f"requant/{i}/s_out"])
+        out = np.empty((rows, C), {8: np.int8, 16: np.int16}[bits])
+        if f"requant/{i}/z_id" in g.files:
+            di = iv.freeze.dyadic(g[f"requant/{i}/s_id"], g[f"requant/{i}/s_out"])
+            zid = np.ascontiguousarray(g[f"requant/{i}/z_id"])
+            assert twin.ivit_cpu_requant_f32(None, hp(z), hp(d), d.shape[0], hp(zid), hp(di), bits, hp(out), rows, C) == 0
+        else:
+            assert twin.ivit_cpu_requant_f32(None, hp(z), hp(d), d.shape[0], None, None, bits, hp(out), rows, C) == 0
+        assert np.array_equal(out.astype(np.int32), g[f"requant/{i}/out"]), i
+
+
+def test_twin_rejects_bad_arguments(twin):
+    """error behaviour of the C-ABI: status codes, never a crash"""
+    x = np.zeros((4, 16), np.int8)
+    assert twin.ivit_cpu_shiftmax(None, None, 4, 16, 16, 0.1, 16, hp(np.zeros((4, 16), np.uint16)), 16) == 1
+    assert twin.ivit_cpu_shiftmax(None, hp(x), 4, 16, 8, 0.1, 16, hp(np.zeros((4, 16), np.uint16)), 16) == 1   # ld_in < n
+    assert twin.ivit_cpu_linear_i8_requant(None, hp(x), hp(x), None, None, 8, hp(x), 4, 4, 16) == 1          # no dyadics
+
+
+# ---------------------------------------------------------------- the same calls through both libraries
+def _cases(rng):
+    """-> list of (entry point, args); an argument is a scalar / Dyadic, ("in", array), ("out", array) or None"""
+    I, O = (lambda a: ("in", np.ascontiguousarray(a))), (lambda a: ("out", a))
+    cs = []
+    M, N, K = 300, 96, 64
+    x = rng.integers(-128, 128, (M, K), dtype=np.int8)
+    w = np.rint(rng.normal(0, 40, (N, K)).clip(-127, 127)).astype(np.int8)
+    b = rng.integers(-3000, 3000, N).astype(np.int32)
+    s_pre = (10 ** rng.uniform(-5.5, -4.5, N)).astype(np.float32)
+    d8, d16 = iv.freeze.dyadic(s_pre, np.float32(2e-2)), iv.freeze.dyadic(s_pre, np.float32(1e-4))
+    dm, dr = iv.freeze.dyadic(np.float32(1e-4), np.float32(2e-4)), iv.freeze.dyadic(np.float32(3e-4), np.float32(2e-4))
+    res = rng.integers(-20000, 20000, (M, N)).astype(np.int16)
+    cs.append(("quantize_input_f32", [I(rng.normal(0, 1, 5000).astype(np.float32)), 0.02, O(np.zeros(5000, np.int8)), 5000]))
+    cs.append(("linear_i8", [I(x), I(w), I(b), O(np.zeros((M, N), np.int32)), M, N, K]))
+    cs.append(("linear_i8_requant", [I(x), I(w), I(b), I(d8), 8, O(np.zeros((M, N), np.int8)), M, N, K]))
+    cs.append(("linear_i8_requant", [I(x), I(w), I(b), I(d16), 16, O(np.zeros((M, N), np.int16)), M, N, K]))
+    cs.append(("linear_i8_requant_residual", [I(x), I(w), I(b), I(d16), dyv(dm), dyv(dr), I(res), O(np.zeros((M, N), np.int16)), M, N, K]))
+    # attention-shaped entry points: B = 2, H = 2, T = 50, dh = 64
+    B, Hh, T, dh, ld = 2, 2, 50, 64, 64
+    D = Hh * dh
+    xq = rng.integers(-128, 128, (B * T, D), dtype=np.int8)
+    wq = np.rint(rng.normal(0, 30, (3 * D, D)).clip(-127, 127)).astype(np.int8)
+    bq = rng.integers(-3000, 3000, 3 * D).astype(np.int32)
+    dq = iv.freeze.dyadic((10 ** rng.uniform(-5.5, -5.0, 3 * D)).astype(np.float32), np.float32(4e-2))
+    q = rng.integers(-128, 128, (B * Hh, T, dh), dtype=np.int8)
+    k = rng.integers(-128, 128, (B * Hh, T, dh), dtype=np.int8)
+    vt = np.zeros((B * Hh, dh, ld), np.int8)
+    vt[:, :, :T] = rng.integers(-128, 128, (B * Hh, dh, T), dtype=np.int8)
+    dqk, dpv = iv.freeze.dyadic(np.float32(2e-4), np.float32(6e-2)), iv.freeze.dyadic(np.float32(3e-6), np.float32(9e-3))
+    cs.append(("linear_i8_qkv", [I(xq), I(wq), I(bq), I(dq), O(np.zeros((B * Hh, T, dh), np.int8)), O(np.zeros((B * Hh, T, dh), np.int8)),
+                                 O(np.zeros((B * Hh, dh, ld), np.int8)), B, T, Hh, dh, ld]))
+    cs.append(("bmm_nt_i8", [I(q), I(k), O(np.zeros((B * Hh, T, T), np.int32)), B * Hh, T, T, dh, dh, dh, T, T * dh, T * dh, T * T]))
+    p16 = np.zeros((B * Hh, T, ld), np.uint16)
+    p16[:, :, :T] = rng.integers(0, 32769, (B * Hh, T, T)).astype(np.uint16)
+    cs.append(("bmm_nt_u16i8", [I(p16), I(vt), O(np.zeros((B * Hh, T, dh), np.int32)), B * Hh, T, dh, T, ld, ld, dh, T * ld, dh * ld, T * dh]))
+    cs.append(("attn_qk_requant", [I(q), I(k), dyv(dqk), O(np.zeros((B * Hh, T, ld), np.int8)), B * Hh, T, dh, ld]))
+    cs.append(("attn_pv_requant", [I(p16), I(vt), dyv(dpv), O(np.zeros((B, T, D), np.int8)), B, Hh, T, dh, ld, ld]))
+    cs.append(("attention_fused", [I(q), I(k), I(vt), dyv(dqk), 0.06, dyv(dpv), O(np.zeros((B, T, D), np.int8)), B, Hh, T, dh, ld]))
+    # requant flavours
+    z32 = rng.integers(-2 ** 20, 2 ** 20, (M, N)).astype(np.int32)
+    zid = rng.integers(-30000, 30000, (M, N)).astype(np.int32)
+    cs.append(("requant_i32", [I(z32), I(d8), N, None, None, 8, O(np.zeros((M, N), np.int8)), M, N]))
+    cs.append(("requant_i32", [I(z32), I(dm), 1, I(zid), I(dr), 16, O(np.zeros((M, N), np.int16)), M, N]))
+    cs.append(("requant_i16", [I(res), I(dm), 1, None, None, 16, O(np.zeros((M, N), np.int16)), M, N]))
+    cs.append(("requant_f32", [I(z32.astype(np.float32) * 4096.0), I(iv.freeze.dyadic(s_pre * np.float32(1e-3), np.float32(2e-2))), N,
+                               None, None, 8, O(np.zeros((M, N), np.int8)), M, N]))
+    # elementwise operators
+    s8 = rng.integers(-128, 128, (64, 197), dtype=np.int8)
+    s8[3] = -128; s8[4] = 127; s8[5, :] = -100; s8[5, 17] = 90                       # flat, saturated and peaky rows
+    cs.append(("shiftmax", [I(s8), 64, 197, 197, 0.07, 16, O(np.zeros((64, 197), np.uint16)), 197]))
+    cs.append(("shiftmax", [I(s8), 64, 197, 197, 0.11, 8, O(np.zeros((64, 197), np.uint16)), 197]))
+    g8 = rng.integers(-128, 128, (40, 384), dtype=np.int8)
+    g8[2] = rng.integers(-128, -60, 384, dtype=np.int8)                               # an all-negative row
+    dg = iv.freeze.dyadic(np.float32(0.03 * 2.0 ** -7), np.float32(0.025))
+    tab = np.zeros(65536, np.int8)
+    cs.append(("shiftgelu", [I(g8), 40, 384, 0.03, O(np.zeros((40, 384), np.int16))]))
+    cs.append(("shiftgelu_requant", [I(g8), 40, 384, 0.03, dyv(dg), O(np.zeros((40, 384), np.int8))]))
+    cs.append(("shiftgelu_build_table", [0.03, dyv(dg), O(tab)]))
+    C = 192
+    xl = rng.integers(-9000, 9000, (48, C)).astype(np.int16)
+    xl[1] = 1234                                                                       # a zero-variance row
+    wl, bl = rng.uniform(0.4, 1.6, C).astype(np.float32), rng.normal(0, 0.3, C).astype(np.float32)
+    wl[5] = -0.7
+    bias_int, sc = iv.freeze.layernorm_constants(wl, bl)
+    dl = iv.freeze.dyadic(sc, np.float32(0.03))
+    cs.append(("layernorm", [I(xl), 48, C, 2.5e-4, I(bias_int), I(sc), O(np.zeros((48, C), np.float32))]))
+    cs.append(("layernorm_requant", [I(xl), 48, C, C, 2.5e-4, I(bias_int), I(sc), I(dl), O(np.zeros((48, C), np.int8))]))
+    img = rng.integers(-128, 128, (2, 3, 32, 32), dtype=np.int8)
+    cs.append(("im2col_patch", [I(img), 2, 3, 32, 32, 8, O(np.zeros((2 * 16, 3 * 64), np.int8))]))
+    Te, De = 17, 64
+    cs.append(("embed_finish", [I(rng.integers(-20000, 20000, (2, Te - 1, De)).astype(np.int16)), I(rng.integers(-10 ** 6, 10 ** 6, De).astype(np.int32)),
+                                I(rng.integers(-20000, 20000, (Te, De)).astype(np.int16)), dyv(dm), dyv(dr), O(np.zeros((2, Te, De), np.int16)), 2, Te, De]))
+    return cs
+
+
+def _run(fn, handle, args, to_ptr):
+    outs, call = [], [handle]
+    for a in args:
+        if isinstance(a, tuple):
+            buf = to_ptr(a[1], a[0] == "out")
+            call.append(buf[0])
+            if a[0] == "out":
+                outs.append(buf[1])
+        else:
+            call.append(a)
+    st = fn(*call)
+    assert st == 0, st
+    return outs
+
+
+@pytest.mark.gpu
+def test_every_twinned_entry_point_agrees_with_the_hip_library(twin):
+    import torch
+    H = _lib.Handle(0, torch.cuda.current_stream().cuda_stream)
+    keep = []
+
+    def to_dev(a, is_out):
+        t = torch.from_numpy(a.copy()).cuda()
+        keep.append(t)
+        return _P(t.data_ptr()), t
+
+    def to_host(a, is_out):
+        h = a.copy()
+        keep.append(h)
+        return hp(h), h
+
+    cases = _cases(np.random.default_rng(77))
+    seen = set()
+    for name, args in cases:
+        seen.add(name)
+        gfn = getattr(H.lib, "ivit_" + name)
+        gfn.argtypes = _sig(name)
+        gout = _run(gfn, H.h, args, to_dev)
+        cout = _run(getattr(twin, "ivit_cpu_" + name), None, args, to_host)
+        torch.cuda.synchronize()
+        for i, (g, c) in enumerate(zip(gout, cout)):
+            g = g.cpu().numpy()
+            if name == "shiftgelu_build_table":       # entries with Q > row max are never indexed (twin leaves them 0)
+                idx = np.arange(65536)
+                valid = (idx & 255) <= (idx >> 8)
+                g, c = g[valid], c[valid]
+            if name == "linear_i8_qkv" and i == 2:    # pad columns of v^T (t >= T) are not written by either side
+                g, c = g[:, :, :50], c[:, :, :50]
+            if name == "attn_qk_requant":
+                g, c = g[:, :, :50], c[:, :, :50]
+            assert np.array_equal(g, c), (name, i, int((g != c).sum()))
+    # planned entry points: same plan-handle protocol on both sides
+    rng = np.random.default_rng(5)
+    M, N, K = 700, 384, 384
+    x = rng.integers(-128, 128, (M, K), dtype=np.int8)
+    w = np.rint(rng.normal(0, 40, (N, K)).clip(-127, 127)).astype(np.int8)
+    b = rng.integers(-3000, 3000, N).astype(np.int32)
+    d = iv.freeze.dyadic((10 ** rng.uniform(-5.5, -5.0, N)).astype(np.float32), np.float32(3e-2))
+    xd, wd, bd, dd = (torch.from_numpy(a).cuda() for a in (x, w, b, d))
+    pg, pc = _P(), _P()
+    f = H.lib.ivit_linear_plan_create
+    f.argtypes = _lib.SIGNATURES["ivit_linear_plan_create"]
+    assert f(H.h, _P(wd.data_ptr()), _P(bd.data_ptr()), _P(dd.data_ptr()), N, K, ctypes.byref(pg)) == 0
+    assert twin.ivit_cpu_linear_plan_create(None, hp(w), hp(b), hp(d), N, K, ctypes.byref(pc)) == 0
+    og, oc = torch.zeros(M, N, dtype=torch.int8, device="cuda"), np.zeros((M, N), np.int8)
+    f = H.lib.ivit_linear_i8_requant_planned
+    f.argtypes = _lib.SIGNATURES["ivit_linear_i8_requant_planned"]
+    assert f(H.h, pg, _P(xd.data_ptr()), 8, _P(og.data_ptr()), M) == 0
+    assert twin.ivit_cpu_linear_i8_requant_planned(None, pc, hp(x), 8, hp(oc), M) == 0
+    assert np.array_equal(og.cpu().numpy(), oc)
+    H.lib.ivit_linear_plan_destroy.argtypes = [_P]
+    assert H.lib.ivit_linear_plan_destroy(pg) == 0 and twin.ivit_cpu_linear_plan_destroy(pc) == 0
+    # every twinned single-call entry point was exercised above (plans and the LUT forms have their own protocol)
+    rest = set(gen_twin_header.TWIN) - seen - {"linear_plan_create", "linear_plan_destroy", "linear_plan_query",
+                                                "linear_i8_requant_planned", "linear_i8_requant_residual_planned",
+                                                "linear_i8_qkv_planned", "attention_fused_lut", "shiftgelu_requant_lut", "mlp_fused"}
+    assert not rest, rest
+
+
+def test_twin_composites_match_the_oracle_chain(twin):
+    """fused entry points of the twin against the oracle's own Python-level chaining (tests/test_oracle_golden.py pins that
+    chaining to the reference)"""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(3)
+    M, C, Hd = 70, 96, 384
+    x = rng.integers(-128, 128, (M, C), dtype=np.int8)
+    w1 = np.rint(rng.normal(0, 40, (Hd, C)).clip(-127, 127)).astype(np.int8)
+    w2 = np.rint(rng.normal(0, 40, (C, Hd)).clip(-127, 127)).astype(np.int8)
+    b1, b2 = rng.integers(-2000, 2000, Hd).astype(np.int32), rng.integers(-2000, 2000, C).astype(np.int32)
+    s1 = (10 ** rng.uniform(-5.3, -5.0, Hd)).astype(np.float32)
+    s2 = (10 ** rng.uniform(-5.3, -5.0, C)).astype(np.float32)
+    s_h, s_g, s_t, s_res, s_fin = (np.float32(v) for v in (0.04, 0.03, 2e-4, 3e-4, 2.5e-4))
+    res = rng.integers(-20000, 20000, (M, C)).astype(np.int16)
+    d1, d2 = iv.freeze.dyadic(s1, s_h), iv.freeze.dyadic(s2, s_t)
+    dg = iv.freeze.dyadic(np.float32(s_h * np.float32(2.0 ** -7)), s_g)
+    dm, dr = iv.freeze.dyadic(s_t, s_fin), iv.freeze.dyadic(s_res, s_fin)
+    tab = np.zeros(65536, np.int8)
+    assert twin.ivit_cpu_shiftgelu_build_table(None, float(s_h), dyv(dg), hp(tab)) == 0
+    out = np.zeros((M, C), np.int16)
+    assert twin.ivit_cpu_mlp_fused(None, hp(x), hp(w1), hp(b1), hp(d1), hp(tab), hp(w2), hp(b2), hp(d2), dyv(dm), dyv(dr),
+                                   hp(res), hp(out), M, C, Hd) == 0
+    h8 = orc.requant(orc.linear_i8(x, w1, b1), orc.dyadic(s1, s_h), 8).astype(np.int8)
+    g8 = orc.requant(orc.shiftgelu(h8, s_h).astype(np.int32), orc.dyadic(np.float32(s_h * np.float32(2.0 ** -7)), s_g), 8).astype(np.int8)
+    t = orc.requant(orc.linear_i8(g8, w2, b2), orc.dyadic(s2, s_t), 16)
+    ref = orc.requant(t, orc.dyadic(s_t, s_fin), 16, res.astype(np.int32), orc.dyadic(s_res, s_fin))
+    assert np.array_equal(out.astype(np.int32), ref)
