@@ -106,8 +106,10 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void attn_fused_kernel(AttnArgs p) 
     if (tid < 256) sXq[tid] = requotient_c((float)(tid - 128), rcp_prepare(p.s_softmax));
     if (LUT) {
         for (int i = tid; i < p.t_count; i += ATT_WAVES * 64) sT[i] = p.et[i];
+        // table offsets are staged as BYTE offsets into sT (x4: t_count <= 16384 keeps them in 16 bits): a score's
+        // table address is then one v_lshl_add_u32 on top of the saturating distance
         for (int i = tid; i < p.nc * 128; i += ATT_WAVES * 64)
-            reinterpret_cast<unsigned *>(sAQ)[i] = reinterpret_cast<const unsigned *>(p.aq)[i];
+            reinterpret_cast<unsigned *>(sAQ)[i] = (reinterpret_cast<const unsigned *>(p.aq)[i] & 0x3fff3fffu) << 2;
         if (tid < 64) reinterpret_cast<unsigned *>(sCls)[tid] = reinterpret_cast<const unsigned *>(p.cls)[tid];
     }
     __syncthreads();
@@ -137,8 +139,11 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void attn_fused_kernel(AttnArgs p) 
         if (q0 + qi < T) qf = *reinterpret_cast<const v4i *>(qg + (q0 + qi) * 64 + g * 16);
 
         // ---- S^T tiles -> requant -> x~ = fl(fl(Q*s)/s) by table; running integer max
+        // LUT form: scores are carried with a bias of VB = 384 (v' = v + 384 in [256, 511]; the bias rides in the requant's
+        // magic constant for free), so that max(v - vmax - dmin, 0) is ONE unsigned saturating subtract
+        constexpr int VB = LUT ? 384 : 0;
         float f[C::NT][4];
-        int qmax = -128;
+        int qmax = -128 + VB;
 #pragma unroll
         for (int j = 0; j < C::NT; ++j) {
             if (j < ntile) {
@@ -148,8 +153,9 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void attn_fused_kernel(AttnArgs p) 
                 acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(kf, qf, acc, 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    int v = FAST ? min(max(rq_fast(acc[r], c_qk), -128), 127) : rq_c((double)acc[r], c_qk, -128, 127);
-                    f[j][r] = LUT ? __int_as_float(v) : sXq[v + 128];      // LUT: the integer itself waits for vmax
+                    int v = FAST ? min(max(__double2loint(__builtin_fma((double)acc[r], c_qk, 6755399441055744.0 + VB)), VB - 128), VB + 127)
+                                 : rq_c((double)acc[r], c_qk, -128, 127) + VB;
+                    f[j][r] = LUT ? __int_as_float(v) : sXq[v + 128];      // LUT: the (biased) integer itself waits for vmax
                     if (j * 16 + 15 < T || j * 16 + g * 4 + r < T) qmax = max(qmax, v);
                 }
             } else {
@@ -159,14 +165,15 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void attn_fused_kernel(AttnArgs p) 
         }
         qmax = max(qmax, __shfl_xor(qmax, 16));
         qmax = max(qmax, __shfl_xor(qmax, 32));
-        const float mx = sXq[qmax + 128];
-        const int rowbase = LUT ? (int)sCls[qmax + 128] * 256 + 128 : 0;
+        const float mx = sXq[qmax + 128 - VB];
+        // byte offset of aq[class(vmax)][v' = 0]: ((class * 256 + 128) - VB) * 2
+        const int rowbase2 = LUT ? ((int)sCls[qmax + 128 - VB] * 256 + 128 - VB) * 2 : 0;
 
         // ---- shift-exp; keys >= T contribute exactly 0
         if (LUT) {
             // two dependent LDS gathers per score, issued as two whole sweeps so the reads of a sweep are all in
             // flight together (one wait per sweep instead of one per score)
-            const int qd = qmax + p.dmin;                       // max(v - vmax, dmin) - dmin == max(v - qd, 0)
+            const unsigned qd = (unsigned)(qmax + p.dmin);      // max(v - vmax, dmin) - dmin == max(v' - qd', 0); qd' >= 1
 #pragma unroll
             for (int j0 = 0; j0 < C::NT; j0 += 4) {             // 16 scores per sweep: bounded extra registers
                 int e1[4][4];
@@ -174,13 +181,16 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void attn_fused_kernel(AttnArgs p) 
                 for (int jj = 0; jj < 4; ++jj)
                     if (j0 + jj < C::NT && j0 + jj < ntile) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) e1[jj][r] = (int)sAQ[rowbase + __float_as_int(f[j0 + jj][r])];
+                        for (int r = 0; r < 4; ++r)
+                            e1[jj][r] = (int)*reinterpret_cast<const unsigned short *>(
+                                reinterpret_cast<const char *>(sAQ) + ((__float_as_int(f[j0 + jj][r]) << 1) + rowbase2));
                     }
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj)
                     if (j0 + jj < C::NT && j0 + jj < ntile) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) e1[jj][r] += max(__float_as_int(f[j0 + jj][r]) - qd, 0);
+                        for (int r = 0; r < 4; ++r)
+                            e1[jj][r] += (int)(__builtin_elementwise_sub_sat((unsigned)__float_as_int(f[j0 + jj][r]), qd) << 2);
                     }
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj)
@@ -188,7 +198,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void attn_fused_kernel(AttnArgs p) 
                         const int j = j0 + jj;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const float e = sT[e1[jj][r]];
+                            const float e = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(sT) + e1[jj][r]);
                             f[j][r] = (j * 16 + 15 < T || j * 16 + g * 4 + r < T) ? e : 0.f;
                         }
                     }
@@ -296,11 +306,15 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void attn_fused_kernel(AttnArgs p) 
                     // e*F16 >= 0: the float -> int conversion truncates, which IS the reference's floor
                     unsigned P0 = (unsigned)(int)(f[j][0] * F16), P1 = (unsigned)(int)(f[j][1] * F16);
                     unsigned P2 = (unsigned)(int)(f[j][2] * F16), P3 = (unsigned)(int)(f[j][3] * F16);
-                    unsigned l01 = __builtin_amdgcn_perm(P1, P0, 0x0c0c0400u), l23 = __builtin_amdgcn_perm(P3, P2, 0x0c0c0400u);
-                    wl = __builtin_amdgcn_perm(l23, l01, 0x05040100u);
-                    unsigned h01 = __builtin_amdgcn_perm(P1 - 16256u, P0 - 16256u, 0x0c0c0501u);
-                    unsigned h23 = __builtin_amdgcn_perm(P3 - 16256u, P2 - 16256u, 0x0c0c0501u);
-                    wh = __builtin_amdgcn_perm(h23, h01, 0x05040100u);
+                    // P <= 2^15: pack pairs as 16-bit halves, subtract 16256 from both halves at once (the low 16 bits of
+                    // P - 16256 are all the hi plane needs), then pick bytes 0 / 1 of each half
+                    typedef unsigned short v2us __attribute__((ext_vector_type(2)));
+                    const unsigned p01 = __builtin_amdgcn_perm(P1, P0, 0x05040100u), p23 = __builtin_amdgcn_perm(P3, P2, 0x05040100u);
+                    wl = __builtin_amdgcn_perm(p23, p01, 0x06040200u);
+                    const v2us off = {16256, 16256};
+                    const unsigned s01 = __builtin_bit_cast(unsigned, (v2us)(__builtin_bit_cast(v2us, p01) - off));
+                    const unsigned s23 = __builtin_bit_cast(unsigned, (v2us)(__builtin_bit_cast(v2us, p23) - off));
+                    wh = __builtin_amdgcn_perm(s23, s01, 0x07050301u);
                 }
                 plo[kb][jj] = (int)wl;
                 phi[kb][jj] = (int)wh;
