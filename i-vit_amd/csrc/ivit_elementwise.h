@@ -379,6 +379,8 @@ __global__ __launch_bounds__(256) void layernorm16_kernel(const int16_t *__restr
             if (__all(same)) break;
         }
         const float F = floorf((1.0f / k) * 2147483648.0f);
+        // fl(fl(y * F) * 0.5) == fl(y * (F * 0.5)): a power-of-two factor commutes with the rounding (no subnormals here)
+        const float Fh = F * 0.5f;
         for (int c = sub; c < nch8; c += 16) {
             const int pc = (c * 8) ^ (((c >> 2) & 3) << 3);
             const v4f a = *reinterpret_cast<const v4f *>(xr + pc), b = *reinterpret_cast<const v4f *>(xr + pc + 4);
@@ -394,7 +396,7 @@ __global__ __launch_bounds__(256) void layernorm16_kernel(const int16_t *__restr
                 rc.d = e < 4 ? sc0[e] : sc1[e - 4];
                 rc.y = e < 4 ? y0[e] : y1[e - 4];
                 const float y = xv - mean;
-                const float yi = floorf((y * F) * 0.5f);
+                const float yi = floorf(y * Fh);
                 const float o = yi + bi;
                 const float zz = rintf(lean_div(o * rc.d, rc));
                 const int v = rq_c((double)zz, cC[e * nch8 + c], -128, 127);
