@@ -639,6 +639,63 @@ __global__ __launch_bounds__(256) void shiftgelu_lut_kernel(const int8_t *__rest
     }
 }
 
+// The same, half a wavefront per row and the row held in registers between the two passes (ITER 16-byte chunks per lane:
+// C = 512 * ITER ... e.g. 1536 -> 3, 3072 -> 6; narrower rows use the tail mask).  One read of the row instead of two, all
+// 64 lanes busy (a 1536-channel row is 96 chunks: 64 + 32 lanes in the one-wave-per-row form), the byte maximum by two
+// v_perm + two v_pk_max_u16 per dword on the biased bytes, table addresses as (byte | row's table base).
+template <int ITER>
+__global__ __launch_bounds__(256) void shiftgelu_lut2_kernel(const int8_t *__restrict__ x, long long rows, int C,
+                                                             const int8_t *__restrict__ tab, int8_t *__restrict__ out) {
+    __shared__ __attribute__((aligned(256))) unsigned char lut[8][256];
+    typedef unsigned short v2us __attribute__((ext_vector_type(2)));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l32 = lane & 31;
+    const int slot = wave * 2 + half;
+    const long long row_raw = (long long)blockIdx.x * 8 + slot;
+    const bool live = row_raw < rows;
+    const long long row = live ? row_raw : rows - 1;            // a dead half-wave recomputes the last row, stores nothing
+    const int8_t *xp = x + row * C;
+    const int nch = C >> 4;
+    v4i v[ITER];
+    v2us me = {0, 0}, mo = {0, 0};                              // running maxima of the even / odd bytes (biased, unsigned)
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int c = l32 + it * 32;
+        v4i t = {(int)0x80808080u, (int)0x80808080u, (int)0x80808080u, (int)0x80808080u};     // -128: neutral for the max
+        if (c < nch) t = *reinterpret_cast<const v4i *>(xp + c * 16);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const unsigned w = (unsigned)t[d] ^ 0x80808080u;    // Q + 128 per byte
+            t[d] = (int)w;
+            me = __builtin_elementwise_max(me, __builtin_bit_cast(v2us, __builtin_amdgcn_perm(0u, w, 0x0c020c00u)));
+            mo = __builtin_elementwise_max(mo, __builtin_bit_cast(v2us, __builtin_amdgcn_perm(0u, w, 0x0c030c01u)));
+        }
+        v[it] = t;
+    }
+    const v2us m2 = __builtin_elementwise_max(me, mo);
+    int qb = max((int)m2[0], (int)m2[1]);                       // biased row maximum of this lane
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) qb = max(qb, __shfl_xor(qb, o));
+    // this row's 256-byte table line: lanes 0..31 of the half copy 8 bytes each
+    reinterpret_cast<v2i *>(lut[slot])[l32] = reinterpret_cast<const v2i *>(tab + (size_t)qb * 256)[l32];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lut[slot];
+    typedef __attribute__((address_space(3))) const unsigned char lds_u8;
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int c = l32 + it * 32;
+        v4i o;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const unsigned w = (unsigned)v[it][d];
+            const unsigned b0 = *(lds_u8 *)(base | (w & 0xffu)), b1 = *(lds_u8 *)(base | ((w >> 8) & 0xffu));
+            const unsigned b2 = *(lds_u8 *)(base | ((w >> 16) & 0xffu)), b3 = *(lds_u8 *)(base | (w >> 24));
+            o[d] = (int)(b0 | (b1 << 8) | (b2 << 16) | (b3 << 24));
+        }
+        if (live && c < nch) *reinterpret_cast<v4i *>(out + row * C + c * 16) = o;
+    }
+}
+
 // diagnostics: lean_div vs the compiler's IEEE division, element-wise
 __global__ __launch_bounds__(256) void debug_div_kernel(const float *__restrict__ n, const float *__restrict__ d,
                                                         float *__restrict__ q_ieee, float *__restrict__ q_lean,

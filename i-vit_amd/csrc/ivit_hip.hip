@@ -691,7 +691,16 @@ int ivit_shiftgelu_requant_lut(ivit_handle h, const int8_t *x, int64_t rows, int
     CHECK_H(h);
     REQUIRE(h, x && out8 && table && rows > 0 && C > 0, "bad arguments");
     REQUIRE(h, (C % 16) == 0, "C must be a multiple of 16");
-    shiftgelu_lut_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, h->stream>>>(x, rows, C, table, out8);
+    // half a wavefront per row, row in registers: ITER = ceil(C / 512) chunks of 16 bytes per lane
+    static const int lut_old = env_int("IVIT_GELU_OLD", 0);
+    const int iter = (C / 16 + 31) / 32;
+    const unsigned grid2 = (unsigned)((rows + 7) / 8);
+    if (lut_old || iter > 6) shiftgelu_lut_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, h->stream>>>(x, rows, C, table, out8);
+    else if (iter == 1) shiftgelu_lut2_kernel<1><<<grid2, 256, 0, h->stream>>>(x, rows, C, table, out8);
+    else if (iter == 2) shiftgelu_lut2_kernel<2><<<grid2, 256, 0, h->stream>>>(x, rows, C, table, out8);
+    else if (iter == 3) shiftgelu_lut2_kernel<3><<<grid2, 256, 0, h->stream>>>(x, rows, C, table, out8);
+    else if (iter == 4) shiftgelu_lut2_kernel<4><<<grid2, 256, 0, h->stream>>>(x, rows, C, table, out8);
+    else shiftgelu_lut2_kernel<6><<<grid2, 256, 0, h->stream>>>(x, rows, C, table, out8);
     LAUNCH_CHECK(h);
     return IVIT_OK;
 }
