@@ -688,8 +688,8 @@ __global__ __launch_bounds__(256) void shiftgelu_lut2_kernel(const int8_t *__res
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             const unsigned w = (unsigned)v[it][d];
-            const unsigned b0 = *(lds_u8 *)(base | (w & 0xffu)), b1 = *(lds_u8 *)(base | ((w >> 8) & 0xffu));
-            const unsigned b2 = *(lds_u8 *)(base | ((w >> 16) & 0xffu)), b3 = *(lds_u8 *)(base | (w >> 24));
+            const unsigned b0 = *(lds_u8 *)(size_t)(base | (w & 0xffu)), b1 = *(lds_u8 *)(size_t)(base | ((w >> 8) & 0xffu));
+            const unsigned b2 = *(lds_u8 *)(size_t)(base | ((w >> 16) & 0xffu)), b3 = *(lds_u8 *)(size_t)(base | (w >> 24));
             o[d] = (int)(b0 | (b1 << 8) | (b2 << 16) | (b3 << 24));
         }
         if (live && c < nch) *reinterpret_cast<v4i *>(out + row * C + c * 16) = o;

@@ -575,7 +575,7 @@ __device__ __forceinline__ void ga_wait_vm_fast(int n) {
 // 16-byte LDS read at an explicit LDS byte address (one base register + immediate offset)
 __device__ __forceinline__ v4i ga_lds_read16(unsigned lds_addr) {
     typedef __attribute__((address_space(3))) const v4i lds_v4i_t;
-    return *(lds_v4i_t *)(lds_addr);
+    return *(lds_v4i_t *)(size_t)(lds_addr);
 }
 
 // swap the upper-half lanes of `a` with the lower-half lanes of `b`
@@ -1031,7 +1031,7 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
                 int n = 1 << 20;
                 if (HAS_CUR) n = issued - mark[(PP + 1) % GA_NK];
                 if (HAS_CUR && PP == 2) n = min(n, issued - mark_cst);
-                if (RES && HAS_PREV && PP < (EH < 0 ? 2 : 1)) n = min(n, issued - mark_res[PP]);
+                if (RES && HAS_PREV && PP < (EH < 0 ? 2 : 1)) n = min(n, issued - mark_res[PP < 2 ? PP : 0]);
                 if (G3_TRACE && HAS_CUR) { __builtin_amdgcn_sched_barrier(0); trace(PP, 4); }
                 if (HAS_CUR || (RES && HAS_PREV && PP < (EH < 0 ? 2 : 1))) {
                     if (G3_WAIT_TABLE) ga_wait_vm(n);
