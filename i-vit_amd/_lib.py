@@ -9,7 +9,7 @@ import subprocess
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 SO_PATH = os.environ.get("IVIT_LIB") or os.path.join(_CSRC, "libivit_hip.so")
-SOURCES = ["ivit_hip.hip", "ivit_device.h", "ivit_gemm.h", "ivit_elementwise.h", "ivit_attention.h", "ivit_gemm2.h", "ivit_gemm3.h", "ivit_swin.h", "ivit_model.h"]
+SOURCES = ["ivit_hip.hip", "ivit_device.h", "ivit_gemm.h", "ivit_elementwise.h", "ivit_layernorm.h", "ivit_attention.h", "ivit_gemm2.h", "ivit_gemm3.h", "ivit_swin.h", "ivit_model.h"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-pass-failed", "-fPIC", "-shared"]
 
 
@@ -178,6 +178,7 @@ SIGNATURES = {
     "ivit_avgpool_requant": [_P, _P, _I, _I, _I, Dyadic, _P],
     "ivit_layernorm_tokenorder": [_P, _P, _L, _I, _F, _P, _P, _I, _P],
     "ivit_debug_div": [_P, _P, _P, _P, _P, _L],
+    "ivit_debug_requotient": [_P, _P, _P, _P, _P, _L],
     "ivit_im2col_patch": [_P, _P, _I, _I, _I, _I, _I, _P],
     "ivit_embed_finish": [_P, _P, _P, _P, Dyadic, Dyadic, _P, _I, _I, _I],
 }

@@ -9,6 +9,7 @@
 #include <dlfcn.h>
 #include "ivit_device.h"
 #include "ivit_elementwise.h"
+#include "ivit_layernorm.h"
 #include "ivit_gemm.h"
 #include "ivit_attention.h"
 #include "ivit_gemm2.h"
@@ -724,31 +725,41 @@ int ivit_layernorm_requant(ivit_handle h, const int16_t *x, int64_t rows, int C,
     CHECK_H(h);
     REQUIRE(h, x && bias_int && sc && dy_ch && out8 && rows > 0 && C > 0 && scale > 0.f, "bad arguments");
     REQUIRE(h, (C % 8) == 0 && (row_stride % 8) == 0 && row_stride >= C, "C, row_stride multiples of 8");
-    {   // production form: 16 lanes per row, constants staged in LDS
+    {   // production form: the row in registers, 4 S lanes per row (ivit_layernorm.h)
+#define LNR_LAUNCH(CC, S)                                                                                      \
+        do {                                                                                                    \
+            constexpr int rpb = (LNR_THREADS(S) / 64) * (64 / (4 * S));                                         \
+            layernorm_reg_kernel<CC, S><<<(unsigned)((rows + rpb - 1) / rpb), LNR_THREADS(S), 0, h->stream>>>( \
+                x, rows, row_stride, scale, bias_int, sc, dy_ch, out8);                                         \
+            LAUNCH_CHECK(h);                                                                                    \
+            return IVIT_OK;                                                                                     \
+        } while (0)
+        switch (C) {
+            // lanes per row = 4 S: <= 64 values per lane (measured on DeiT-S b256: S = 1 23.2 us, S = 2 20.1, S = 4 20.2 —
+            // shorter per-wave instruction chains and more waves per SIMD beat the cheaper quad-only reduction)
+            case 96: LNR_LAUNCH(96, 1);        // Swin-T/S stage 0 (token-order sums use their own kernel)
+            case 128: LNR_LAUNCH(128, 1);      // Swin-B stage 0
+            case 192: LNR_LAUNCH(192, 1);      // DeiT-T, Swin stage 1
+            case 256: LNR_LAUNCH(256, 2);
+            case 384: LNR_LAUNCH(384, 2);      // DeiT-S, Swin stage 2, PatchMerging
+            case 512: LNR_LAUNCH(512, 2);
+            case 768: LNR_LAUNCH(768, 4);      // DeiT-B / ViT-B, Swin stage 3
+            case 1024: LNR_LAUNCH(1024, 4);    // ViT-L
+            case 1536: LNR_LAUNCH(1536, 4);    // Swin PatchMerging before stage 3
+            default: break;
+        }
+#undef LNR_LAUNCH
+    }
+    {   // other channel counts: 16 lanes per row, the row staged in LDS
         const size_t lds16 = (size_t)16 * (C + 16) * 4 + (size_t)C * 20;
-        static const int ln_old = env_int("IVIT_LN_OLD", 0), force_riter = env_int("IVIT_LN_RITER", 0);
-        if (lds16 <= 150 * 1024 && !ln_old) {
-            // row groups per block: up to LN_RITER (amortises the constant staging), fewer when the launch would
-            // otherwise be too coarse: with 3.08 blocks per CU (DeiT-S b256, riter 4) the 20 CUs that get a fourth block
-            // set the kernel's time; >= 6 blocks per CU wanted (measured: 0.76 -> 0.70 ms per forward)
+        if (lds16 <= 150 * 1024) {
             long long riter = rows / (16LL * 6 * h->num_cu);
             riter = riter < 1 ? 1 : (riter > LN_RITER ? LN_RITER : riter);
-            if (force_riter > 0) riter = force_riter;
             const long long per_block = 16 * riter;
             const unsigned grid = (unsigned)((rows + per_block - 1) / per_block);
-#define LN16_LAUNCH(CC)                                                                                   \
-            do {                                                                                          \
-                int st16 = set_dyn_lds(h, (const void *)layernorm16_kernel<CC>, lds16);                   \
-                if (st16) return st16;                                                                    \
-                layernorm16_kernel<CC><<<grid, 256, lds16, h->stream>>>(x, rows, C, row_stride, scale,    \
-                                                                       bias_int, sc, dy_ch, out8, (int)riter); \
-            } while (0)
-            if (C == 384) LN16_LAUNCH(384);          // DeiT-S / Swin stage 2
-            else if (C == 768) LN16_LAUNCH(768);     // DeiT-B, ViT-B / Swin stage 3
-            else if (C == 192) LN16_LAUNCH(192);     // DeiT-T / Swin stage 1
-            else if (C == 1536) LN16_LAUNCH(1536);   // Swin PatchMerging before stage 3
-            else LN16_LAUNCH(0);
-#undef LN16_LAUNCH
+            int st16 = set_dyn_lds(h, (const void *)layernorm16_kernel<0>, lds16);
+            if (st16) return st16;
+            layernorm16_kernel<0><<<grid, 256, lds16, h->stream>>>(x, rows, C, row_stride, scale, bias_int, sc, dy_ch, out8, (int)riter);
             LAUNCH_CHECK(h);
             return IVIT_OK;
         }
@@ -859,6 +870,14 @@ int ivit_debug_div(ivit_handle h, const float *n, const float *d, float *q_ieee,
     CHECK_H(h);
     REQUIRE(h, n && d && q_ieee && q_lean && count > 0, "bad arguments");
     debug_div_kernel<<<(unsigned)((count + 255) / 256), 256, 0, h->stream>>>(n, d, q_ieee, q_lean, count);
+    LAUNCH_CHECK(h);
+    return IVIT_OK;
+}
+
+int ivit_debug_requotient(ivit_handle h, const float *q, const float *d, float *r_ieee, float *r_markstein, int64_t count) {
+    CHECK_H(h);
+    REQUIRE(h, q && d && r_ieee && r_markstein && count > 0, "bad arguments");
+    debug_requotient_kernel<<<(unsigned)((count + 255) / 256), 256, 0, h->stream>>>(q, d, r_ieee, r_markstein, count);
     LAUNCH_CHECK(h);
     return IVIT_OK;
 }

@@ -1,0 +1,237 @@
+// ivit_layernorm.h — I-LayerNorm + per-channel 8-bit requant (a7 + a3), register-resident form.
+//
+// Reference sequence (quant_modules.py:353-386 followed by the next QuantAct, quant_utils.py:213-253; restated in
+// oracle/ivit_oracle.c::ivit_o_layernorm): x = fl(fl(Q*s)/s); mean = rne(SUM(x)/C); y = x - mean; v = SUM(fl(y*y));
+// ten integer Newton steps for sqrt(v); F = floor(2^31/k); o = floor(fl(y*F)/2) + bias_int; z = rne(fl(fl(o*sc)/sc));
+// out = clamp(rne(z*c), -128, 127).  Both SUMs are torch-CPU's vectorised order (ivit_device.h::torch_order_sum32):
+// element 32 i + 8 k + l goes to accumulator (k, l) at step i.
+//
+// Layout: 4 S lanes per row (S = 1, 2, 4 for C <= 384, 768, 1536).  Lane (k, h) of a row owns the 8 / S vector lanes
+// l = (8 / S) h ... of accumulator group k, i.e. the contiguous 16 / S bytes of every 32-element step: the row is read
+// ONCE with plain vector loads, lives in registers as fp32 (C / (4 S) <= 96 values per lane) through both sums and the
+// output pass, and never touches the LDS (the round-2 kernel staged it there, swizzled, and re-read it three times).
+// The accumulator groups of a row meet once per sum: k = 0..3 by DPP quad broadcasts (S = 1) in the reference's order
+// ((a0 + a1) + a2) + a3, then the eight vector lanes sequentially.
+//
+// Divisions by a per-tensor / per-channel constant d: with yd = RN(1/d) and a faithful first guess q0, Markstein's
+// correction q = fma(fma(-d, q0, n), yd, q0) is the correctly rounded n / d.  Here n = fl(q0 * d) for a 24-bit q0
+// (the quotient IS the operand we multiplied by d, up to the product's rounding), so q0 is faithful and the residual
+// fma(q0, d, -n) is exact: three VALU operations instead of the eleven of an IEEE division or the six of the hoisted
+// Newton form (ivit_device.h::lean_div).  Pinned against `/` in tests/test_gpu_parity.py::test_markstein_requotient.
+#pragma once
+#include "ivit_device.h"
+
+// fl(fl(q * d) / d) for a float q with |q| < 2^24 * ulp-safe range, yd = RN(1 / d)
+__device__ __forceinline__ float requotient_m(float q, float d, float yd) {
+    const float n = q * d;
+    const float e = __builtin_fmaf(q, d, -n);       // exact: q*d - fl(q*d)
+    return __builtin_fmaf(-e, yd, q);
+}
+// correctly rounded reciprocal: fl64(1/d) rounded to binary32 cannot sit on a binary32 midpoint unless d is a power of two
+// (then it is exact), so the double rounding is harmless
+__device__ __forceinline__ float rcp_rn(float d) { return (float)(1.0 / (double)d); }
+
+template <int Q>
+__device__ __forceinline__ float ln_quad_bcast(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), Q * 0x55, 0xf, 0xf, true));
+}
+
+// v[lane'] by a DPP control word: 0x100 + n = row_shl:n (lane i reads lane i + n), 0x110 + n = row_shr:n (lane i reads
+// lane i - n), both inside a row of 16 lanes; lanes without a source read 0
+template <int CTRL>
+__device__ __forceinline__ float ln_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
+// 32 rows per block whatever the split: the per-block staging of the channel constants (an fp64 division each) stays ~8 %
+#define LNR_THREADS(S) (128 * (S))
+// timing probes only (tools/ubench/ln_probe.hip): 1 = no output-pass arithmetic, 2 = no second sum, 4 = no Newton loop
+#ifndef LNR_ABLATE
+#define LNR_ABLATE 0
+#endif
+// register budget by lanes per row: 96 / 48 / 24 values per lane -> 4 / 5 / 8 waves per SIMD
+#define LNR_MIN_WAVES(S) ((S) == 1 ? 4 : ((S) == 2 ? 5 : 8))
+template <int CC, int S>
+__global__ __launch_bounds__(LNR_THREADS(S), LNR_MIN_WAVES(S)) void layernorm_reg_kernel(const int16_t *__restrict__ x, long long rows,
+                                                                     long long row_stride, float s,
+                                                                     const float *__restrict__ bias_int,
+                                                                     const float *__restrict__ sc,
+                                                                     const ivit_dyadic *__restrict__ dy,
+                                                                     int8_t *__restrict__ out) {
+    constexpr int LPR = 4 * S, EPC = 8 / S, NSTEP = CC / 32, RPW = 64 / LPR, RPB = (LNR_THREADS(S) / 64) * RPW;
+    static_assert(CC % 32 == 0 && NSTEP < 256, "whole 32-element steps, at most one cascade level above the first");
+    __shared__ __attribute__((aligned(16))) double cC[CC];
+    __shared__ __attribute__((aligned(16))) float cB[CC], cSc[CC], cY[CC];
+    const int tid = threadIdx.x;
+    for (int c = tid; c < CC; c += LNR_THREADS(S)) {
+        const float scv = sc[c];
+        cSc[c] = scv;
+        cY[c] = rcp_rn(scv);
+        cB[c] = bias_int[c];
+        cC[c] = dy[c].m * dy[c].r;
+    }
+    __syncthreads();
+    const int lane = tid & 63, j = lane % LPR, k = j / S, hh = j % S;
+    const long long row_raw = (long long)blockIdx.x * RPB + (tid >> 6) * RPW + lane / LPR;
+    const bool live = row_raw < rows;
+    const long long row = live ? row_raw : rows - 1;          // a dead lane group recomputes the last row, stores nothing
+    const int16_t *xp = x + row * row_stride + 8 * k + EPC * hh;
+    const float ys = rcp_rn(s);
+
+    // ---- pass 1: load, x = fl(fl(Q*s)/s), first sum
+    float xv[NSTEP][EPC];
+    float a0[EPC], a1[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { a0[e] = 0.f; a1[e] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < NSTEP; ++i) {
+        short q[EPC];
+        if constexpr (EPC == 8) {
+            const v8s t = *reinterpret_cast<const v8s *>(xp + 32 * i);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) q[e] = t[e];
+        } else if constexpr (EPC == 4) {
+            typedef short v4s __attribute__((ext_vector_type(4)));
+            const v4s t = *reinterpret_cast<const v4s *>(xp + 32 * i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) q[e] = t[e];
+        } else {
+            typedef short v2s __attribute__((ext_vector_type(2)));
+            const v2s t = *reinterpret_cast<const v2s *>(xp + 32 * i);
+            q[0] = t[0]; q[1] = t[1];
+        }
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) xv[i][e] = requotient_m((float)q[e], s, ys);
+    }
+    auto cascade = [&](int i) {      // torch's level-1 fold after every 16 whole steps
+        if (((i + 1) & 15) == 0 && i + 1 <= (NSTEP & ~15)) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) { a1[e] += a0[e]; a0[e] = 0.f; }
+        }
+    };
+    // ((g0 + g1) + g2) + g3 over the accumulator groups, then vector lanes 0..7 in order; every lane of the row gets it.
+    // Lane j = S k + h of a row: group k + 1 is S lanes up (DPP row shifts; a row's 4 S lanes never straddle a DPP row of
+    // 16), the partial sums are valid on the k = 0 lanes, the total on lane j = 0, from where it is broadcast.
+    auto finish = [&]() -> float {
+        float p[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const float a = NSTEP >= 16 ? a0[e] + a1[e] : a0[e];
+            if constexpr (S == 1) {
+                float t = ln_quad_bcast<0>(a);
+                t += ln_quad_bcast<1>(a);
+                t += ln_quad_bcast<2>(a);
+                t += ln_quad_bcast<3>(a);
+                p[e] = t;
+            } else {
+                float t = a + ln_dpp<0x100 + S>(a);
+                t += ln_dpp<0x100 + 2 * S>(a);
+                t += ln_dpp<0x100 + 3 * S>(a);
+                p[e] = t;
+            }
+        }
+        float fin = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) fin += p[e];
+        if constexpr (S == 2) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) fin += ln_dpp<0x101>(p[e]);
+            const float q0 = ln_quad_bcast<0>(fin), q1 = ln_dpp<0x114>(q0);      // lanes 0..3 | 4..7 of the row
+            fin = (j & 4) ? q1 : q0;
+        } else if constexpr (S == 4) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) fin += ln_dpp<0x101>(p[e]);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) fin += ln_dpp<0x102>(p[e]);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) fin += ln_dpp<0x103>(p[e]);
+            const float q0 = ln_quad_bcast<0>(fin), q1 = ln_dpp<0x114>(q0), q2 = ln_dpp<0x118>(q0), q3 = ln_dpp<0x11c>(q0);
+            fin = k == 0 ? q0 : (k == 1 ? q1 : (k == 2 ? q2 : q3));
+        }
+        return fin;
+    };
+#pragma unroll
+    for (int i = 0; i < NSTEP; ++i) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) a0[e] += xv[i][e];
+        cascade(i);
+    }
+    const float mean = rintf(finish() / (float)CC);
+
+    // ---- pass 2: y = x - mean (kept), second sum
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { a0[e] = 0.f; a1[e] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < NSTEP; ++i) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const float y = xv[i][e] - mean;
+            xv[i][e] = y;
+            if (!(LNR_ABLATE & 2)) a0[e] += y * y;
+        }
+        cascade(i);
+    }
+    const float var = finish();
+    // integer Newton iteration; k' == k is a fixed point of the remaining steps, so the early exit is exact
+    float kk = 65536.0f;
+    for (int n = 0; n < ((LNR_ABLATE & 4) ? 0 : 10); ++n) {
+        const float kn = floorf((kk + floorf(var / kk)) * 0.5f);
+        const bool same = (kn == kk);
+        kk = kn;
+        if (__all(same)) break;
+    }
+    const float F = floorf((1.0f / kk) * 2147483648.0f);
+    const float Fh = F * 0.5f;       // fl(fl(y * F) * 0.5) == fl(y * (F * 0.5)): the power of two commutes with the rounding
+
+    // ---- pass 3: normalise, requotient by the channel scale, 8-bit requant, store
+    int8_t *op = out + row * CC + 8 * k + EPC * hh;
+#pragma unroll
+    for (int i = 0; i < NSTEP; ++i) {
+        const int cb = 32 * i + 8 * k + EPC * hh;
+        float bi[EPC], scv[EPC], yv[EPC];
+        double cv[EPC];
+#pragma unroll
+        for (int e4 = 0; e4 < EPC; e4 += (EPC >= 4 ? 4 : 2)) {
+            if constexpr (EPC >= 4) {
+                const v4f b4 = *reinterpret_cast<const v4f *>(cB + cb + e4), s4 = *reinterpret_cast<const v4f *>(cSc + cb + e4),
+                          y4 = *reinterpret_cast<const v4f *>(cY + cb + e4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { bi[e4 + e] = b4[e]; scv[e4 + e] = s4[e]; yv[e4 + e] = y4[e]; }
+            } else {
+                bi[0] = cB[cb]; bi[1] = cB[cb + 1]; scv[0] = cSc[cb]; scv[1] = cSc[cb + 1]; yv[0] = cY[cb]; yv[1] = cY[cb + 1];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < EPC; e += 2) {
+            typedef double v2d __attribute__((ext_vector_type(2)));
+            const v2d c2 = *reinterpret_cast<const v2d *>(cC + cb + e);
+            cv[e] = c2[0]; cv[e + 1] = c2[1];
+        }
+        unsigned pk[2] = {0, 0};
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const float o = floorf(xv[i][e] * Fh) + bi[e];
+            if (LNR_ABLATE & 1) { pk[e >> 2] |= ((unsigned)__float_as_int(o) & 0xffu) << (8 * (e & 3)); continue; }
+            const float zz = rintf(requotient_m(o, scv[e], yv[e]));
+            const int v = rq_c((double)zz, cv[e], -128, 127);
+            pk[e >> 2] |= ((unsigned)v & 0xffu) << (8 * (e & 3));
+        }
+        if (live) {
+            if constexpr (EPC == 8) *reinterpret_cast<v2i *>(op + 32 * i) = v2i{(int)pk[0], (int)pk[1]};
+            else if constexpr (EPC == 4) *reinterpret_cast<unsigned *>(op + 32 * i) = pk[0];
+            else *reinterpret_cast<unsigned short *>(op + 32 * i) = (unsigned short)pk[0];
+        }
+    }
+}
+
+// diagnostics: requotient_m against the IEEE sequence fl(fl(q*d)/d), element-wise
+__global__ __launch_bounds__(256) void debug_requotient_kernel(const float *__restrict__ q, const float *__restrict__ d,
+                                                               float *__restrict__ r_ieee, float *__restrict__ r_m,
+                                                               long long count) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < count) {
+        const float n = q[i] * d[i];
+        r_ieee[i] = n / d[i];
+        r_m[i] = requotient_m(q[i], d[i], rcp_rn(d[i]));
+    }
+}

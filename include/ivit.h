@@ -406,6 +406,11 @@ int ivit_widen_i8_i16(ivit_handle h, const int8_t *x, int16_t *out, int64_t n);
  * FMA sequence the kernels use for constant divisors; must agree bit for bit.            */
 int ivit_debug_div(ivit_handle h, const float *n, const float *d, float *q_ieee, float *q_lean,
                    int64_t count);
+/* r_ieee = fl(fl(q*d)/d) with the compiler's division and r_markstein = the three-operation form the
+ * I-LayerNorm kernel uses (product, exact residual, one correction with RN(1/d)); must agree bit
+ * for bit (quant_modules.py:359 x / scaling_factor after :204-206 x * scaling_factor).       */
+int ivit_debug_requotient(ivit_handle h, const float *q, const float *d, float *r_ieee, float *r_markstein,
+                          int64_t count);
 
 #ifdef __cplusplus
 }

@@ -79,6 +79,33 @@ def test_lean_division(H):
     assert np.array_equal(a.view(np.int32), b.view(np.int32)), f"{(a != b).sum()} of {n.size} differ"
 
 
+def test_markstein_requotient(H):
+    """fl(fl(q*d)/d) by product + exact residual + one correction with RN(1/d) (ivit_layernorm.h::requotient_m) equals
+    the IEEE sequence bit for bit: every int16 Q against many per-tensor scales (quant_modules.py:204-206 -> :359), and
+    24-bit |o| up to 2^31 against per-channel LayerNorm scales of either sign (quant_modules.py:378-386 -> quant_utils.py:220)."""
+    rng = np.random.default_rng(11)
+    qs, ds = [], []
+    allq = np.arange(-32768, 32768, dtype=np.float32)
+    for s in (10 ** rng.uniform(-6, 0.5, 48)).astype(np.float32):
+        qs.append(allq)
+        ds.append(np.full(allq.size, s, np.float32))
+    for _ in range(600):
+        sc = np.float32(rng.uniform(-1, 1) * 10 ** rng.uniform(-9, -3))
+        if sc == 0:
+            continue
+        o = np.rint(rng.standard_normal(4096) * 2.0 ** rng.integers(8, 31)).astype(np.float32) + np.float32(0)   # no -0.0
+        qs.append(o)
+        ds.append(np.full(4096, sc, np.float32))
+    q = np.concatenate(qs)
+    d = np.concatenate(ds)
+    a = torch.empty(q.size, dtype=torch.float32, device="cuda")
+    b = torch.empty_like(a)
+    H.call("ivit_debug_requotient", P(dev(q)), P(dev(d)), P(a), P(b), q.size)
+    a, b = a.cpu().numpy(), b.cpu().numpy()
+    assert np.array_equal(a, ((q * d).astype(np.float32) / d).astype(np.float32))     # GPU IEEE == host IEEE
+    assert np.array_equal(a.view(np.int32), b.view(np.int32)), f"{(a != b).sum()} of {q.size} differ"
+
+
 def test_quantize_input(H, ops_golden):
     g = ops_golden
     x = dev(g["quant_in/x"])
