@@ -9,7 +9,7 @@ import subprocess
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 SO_PATH = os.environ.get("IVIT_LIB") or os.path.join(_CSRC, "libivit_hip.so")
-SOURCES = ["ivit_hip.hip", "ivit_device.h", "ivit_gemm.h", "ivit_elementwise.h", "ivit_layernorm.h", "ivit_attention.h", "ivit_gemm2.h", "ivit_gemm3.h", "ivit_swin.h", "ivit_model.h"]
+SOURCES = ["ivit_hip.hip", "ivit_device.h", "ivit_gemm.h", "ivit_elementwise.h", "ivit_layernorm.h", "ivit_attention.h", "ivit_gemm2.h", "ivit_gemm3.h", "ivit_swin.h", "ivit_mlp.h", "ivit_model.h"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-pass-failed", "-fPIC", "-shared"]
 
 
@@ -132,6 +132,8 @@ SIGNATURES = {
     "ivit_layernorm_tokenorder_requant": [_P, _P, _L, _I, _F, _P, _P, _P, _I, _P],
     "ivit_patch_norm_tokenorder": [_P, _P, _L, _I, _F, _P, _P, _P, Dyadic, _I, _P],
     "ivit_window_attention_fused": [_P, _P, Dyadic, Dyadic, _P, _F, Dyadic, _P, _I, _I, _I, _I, _I, _I],
+    "ivit_mlp_plan_create": [_P, _P, _P, ctypes.POINTER(_P)],
+    "ivit_mlp_fused_planned": [_P, _P, _P, _P, Dyadic, Dyadic, _P, _P, _L],
     "ivit_mlp_fused": [_P, _P, _P, _P, _P, _P, _P, _P, _P, Dyadic, Dyadic, _P, _P, _L, _I, _I],
     "ivit_patch_merge_gather": [_P, _P, _I, _I, _I, _I, _P],
     "ivit_widen_i8_i16": [_P, _P, _P, _L],
@@ -182,7 +184,7 @@ SIGNATURES = {
     "ivit_im2col_patch": [_P, _P, _I, _I, _I, _I, _I, _P],
     "ivit_embed_finish": [_P, _P, _P, _P, Dyadic, Dyadic, _P, _I, _I, _I],
 }
-OTHER_SYMBOLS = ["ivit_version", "ivit_status_string", "ivit_last_error", "ivit_linear_plan_destroy", "ivit_linear_plan_query", "ivit_debug_plan_scratch"]
+OTHER_SYMBOLS = ["ivit_version", "ivit_status_string", "ivit_last_error", "ivit_linear_plan_destroy", "ivit_mlp_plan_destroy", "ivit_linear_plan_query", "ivit_debug_plan_scratch"]
 
 _lib = None
 

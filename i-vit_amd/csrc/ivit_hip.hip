@@ -15,6 +15,7 @@
 #include "ivit_gemm2.h"
 #include "ivit_gemm3.h"
 #include "ivit_swin.h"
+#include "ivit_mlp.h"
 
 struct ivit_ctx {
     int device;
@@ -512,6 +513,78 @@ int ivit_linear_i8_qkv_planned(ivit_handle h, ivit_linear_plan pl, const int8_t 
     a.T = T; a.H = H; a.dh = dh; a.ldv = ldv; a.D = D;
     if (use_gemm3(pl, a, 2) && (long long)B * T < (1 << 23)) return launch_gemm3<EPI_QKV>(h, pl, a);
     return ivit_linear_i8_qkv(h, x, pl->w, pl->bias, pl->dy, q, k, vt, B, T, H, dh, ldv);
+}
+
+}  // extern "C"
+
+// ---- fused Mlp (+ residual QuantAct) for D = 384, hidden = 1536 (ivit_mlp.h)
+struct ivit_mlp_plan_s {
+    ivit_linear_plan fc1, fc2;      // borrowed: must outlive this plan
+    v4i *w1f, *w2f;                 // fragment-ordered copies of the two weight matrices (one allocation)
+    int fma;                        // both layers: one fused rounding == the reference's two
+    int device;
+};
+
+extern "C" {
+
+int ivit_mlp_plan_create(ivit_handle h, ivit_linear_plan fc1, ivit_linear_plan fc2, ivit_mlp_plan *out) {
+    CHECK_H(h);
+    REQUIRE(h, fc1 && fc2 && out, "null argument");
+    if (fc1->K != MLP_C || fc1->N != MLP_HD || fc2->K != MLP_HD || fc2->N != MLP_C) {
+        snprintf(h->err, sizeof(h->err), "%s: built for 384 -> 1536 -> 384", __func__);
+        return IVIT_ERR_UNSUPPORTED;
+    }
+    if (!fc1->pipelined_ok || !fc2->pipelined_ok) {
+        snprintf(h->err, sizeof(h->err), "%s: |(acc + bias) * c| < 2^31 not provable for these weights", __func__);
+        return IVIT_ERR_UNSUPPORTED;
+    }
+    const size_t wbytes = (size_t)MLP_C * MLP_HD;
+    char *dev = nullptr;
+    if (hipMalloc((void **)&dev, 2 * wbytes) != hipSuccess) { snprintf(h->err, sizeof(h->err), "%s: hipMalloc failed", __func__); return IVIT_ERR_HIP; }
+    mlp_swizzle_kernel<<<256, 256, 0, h->stream>>>(fc1->w, MLP_HD, MLP_C, (v4i *)dev);
+    mlp_swizzle_kernel<<<256, 256, 0, h->stream>>>(fc2->w, MLP_C, MLP_HD, (v4i *)(dev + wbytes));
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) {     // plan creation is a build-time call
+        (void)hipFree(dev);
+        snprintf(h->err, sizeof(h->err), "%s: HIP error", __func__);
+        return IVIT_ERR_HIP;
+    }
+    ivit_mlp_plan_s *p = new (std::nothrow) ivit_mlp_plan_s();
+    if (!p) { (void)hipFree(dev); return IVIT_ERR_HIP; }
+    p->fc1 = fc1; p->fc2 = fc2; p->w1f = (v4i *)dev; p->w2f = (v4i *)(dev + wbytes);
+    p->fma = fc1->single_fma_ok && fc2->single_fma_ok;
+    p->device = h->device;
+    *out = p;
+    return IVIT_OK;
+}
+
+int ivit_mlp_plan_destroy(ivit_mlp_plan p) {
+    if (!p) return IVIT_ERR_INVALID;
+    (void)hipFree(p->w1f);
+    delete p;
+    return IVIT_OK;
+}
+
+int ivit_mlp_fused_planned(ivit_handle h, ivit_mlp_plan p, const int8_t *x, const int8_t *gelu_table, ivit_dyadic dy_main,
+                           ivit_dyadic dy_res, const int16_t *residual, int16_t *out, int64_t M) {
+    CHECK_H(h);
+    REQUIRE(h, p && x && gelu_table && residual && out && M > 0, "bad arguments");
+    MlpArgs a;
+    a.x = x; a.w1f = p->w1f; a.w2f = p->w2f; a.b1 = p->fc1->bias_eff; a.b2 = p->fc2->bias_eff;
+    a.cq1 = p->fc1->cq; a.cq2 = p->fc2->cq; a.tab = gelu_table; a.residual = residual; a.out = out;
+    a.cm = dy_main.m * dy_main.r; a.cr = dy_res.m * dy_res.r; a.M = M; a.trace = nullptr;
+    if (!(fabs(a.cm) < RQ_FAST_CLIM && fabs(a.cr) < RQ_FAST_CLIM)) {
+        snprintf(h->err, sizeof(h->err), "%s: residual multipliers out of the fast range", __func__);
+        return IVIT_ERR_UNSUPPORTED;
+    }
+    const void *fn = p->fma ? (const void *)mlp384_kernel<true> : (const void *)mlp384_kernel<false>;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_SMEM);
+    if (e != hipSuccess) { snprintf(h->err, sizeof(h->err), "%s: attr: %s", __func__, hipGetErrorString(e)); return IVIT_ERR_HIP; }
+    const long long nunits = (M + MLP_BM - 1) / MLP_BM;
+    const unsigned grid = (unsigned)(nunits < h->num_cu ? nunits : h->num_cu);
+    if (p->fma) mlp384_kernel<true><<<grid, MLP_THREADS, MLP_SMEM, h->stream>>>(a);
+    else mlp384_kernel<false><<<grid, MLP_THREADS, MLP_SMEM, h->stream>>>(a);
+    LAUNCH_CHECK(h);
+    return IVIT_OK;
 }
 
 }  // extern "C"

@@ -14,6 +14,7 @@ struct ivit_vit_s {
     bool fused_attention;
     int8_t *gelu_tab;                 // [depth][65536]
     std::vector<ivit_linear_plan> plans;   // per block: qkv, proj, fc1, fc2 (frozen QuantLinear plans, ivit_linear_plan_create)
+    std::vector<ivit_mlp_plan> mlp_plans;  // per block: fused Mlp plan (D = 384), or null -> fc1 / ShiftGELU / fc2 launches
     int max_slices;
     std::vector<ivit_handle> slice_h; // one handle per internal stream
     std::vector<hipStream_t> streams;
@@ -104,9 +105,15 @@ int run_slice(const ivit_vit_s *m, ivit_handle h, const int8_t *images, int B, i
         RUN(ivit_linear_i8_requant_residual_planned(h, m->plans[4 * i + 1], ctx8, b.res1_main, b.res1_res, x, y, M));
         { int16_t *t = x; x = y; y = t; }
         RUN(ivit_layernorm_requant(h, x, M, D, D, b.s_ln2, b.n2_bias_int, b.n2_sc, b.n2_dy, a8));
-        RUN(ivit_linear_i8_requant_planned(h, m->plans[4 * i + 2], a8, 8, h8, M));
-        RUN(ivit_shiftgelu_requant_lut(h, h8, M, Hd, m->gelu_tab + (size_t)i * 65536, g8));
-        RUN(ivit_linear_i8_requant_residual_planned(h, m->plans[4 * i + 3], g8, b.res2_main, b.res2_res, x, y, M));
+        const bool mlp_fast = m->mlp_plans[i] && fabs(b.res2_main.m * b.res2_main.r) < RQ_FAST_CLIM &&
+                              fabs(b.res2_res.m * b.res2_res.r) < RQ_FAST_CLIM;
+        if (mlp_fast) {     // hidden tensor stays in LDS
+            RUN(ivit_mlp_fused_planned(h, m->mlp_plans[i], a8, m->gelu_tab + (size_t)i * 65536, b.res2_main, b.res2_res, x, y, M));
+        } else {
+            RUN(ivit_linear_i8_requant_planned(h, m->plans[4 * i + 2], a8, 8, h8, M));
+            RUN(ivit_shiftgelu_requant_lut(h, h8, M, Hd, m->gelu_tab + (size_t)i * 65536, g8));
+            RUN(ivit_linear_i8_requant_residual_planned(h, m->plans[4 * i + 3], g8, b.res2_main, b.res2_res, x, y, M));
+        }
         { int16_t *t = x; x = y; y = t; }
     }
     // final norm on the class-token rows only (row stride T*D), then the head's int32 accumulators
@@ -166,6 +173,9 @@ int ivit_vit_create(ivit_handle h, const ivit_vit_config *cfg, const ivit_vit_pa
             if (rc != IVIT_OK) { ivit_vit_destroy(m); return rc; }
             m->plans.push_back(pl);
         }
+        ivit_mlp_plan mp = nullptr;
+        if (D == MLP_C && Hd == MLP_HD && ivit_mlp_plan_create(h, m->plans[4 * i + 2], m->plans[4 * i + 3], &mp) != IVIT_OK) mp = nullptr;
+        m->mlp_plans.push_back(mp);
     }
     if (max_slices > 1) {
         bool ok = hipEventCreateWithFlags(&m->fork, hipEventDisableTiming) == hipSuccess;
@@ -198,6 +208,7 @@ int ivit_vit_destroy(ivit_vit m) {
     for (auto st : m->streams) (void)hipStreamDestroy(st);
     if (m->fork) (void)hipEventDestroy(m->fork);
     if (m->gelu_tab) (void)hipFree(m->gelu_tab);
+    for (auto mp : m->mlp_plans) if (mp) (void)ivit_mlp_plan_destroy(mp);
     for (auto pl : m->plans) (void)ivit_linear_plan_destroy(pl);
     delete m;
     return IVIT_OK;

@@ -396,6 +396,18 @@ int ivit_mlp_fused(ivit_handle h, const int8_t *x, const int8_t *w1, const int32
                    const int8_t *gelu_table, const int8_t *w2, const int32_t *b2, const ivit_dyadic *dy2,
                    ivit_dyadic dy_main, ivit_dyadic dy_res, const int16_t *residual, int16_t *out, int64_t M,
                    int C, int hidden);
+/* The same chain for C = 384, hidden = 1536 (DeiT-S, Swin stage 2) on frozen linear plans: both weight matrices are
+ * re-laid-out once in MFMA-fragment order and stream L2 -> registers, the hidden tile of 64 tokens lives in LDS between
+ * fc1, the ShiftGELU table pass and fc2 (csrc/ivit_mlp.h).  The linear plans are borrowed and must outlive the Mlp plan.
+ * IVIT_ERR_UNSUPPORTED for other shapes, for plans whose requant bound is not provable, and (at call time) for
+ * residual multipliers >= 2^9: callers then run the unfused chain.  Replaces layers_quant.py:144-153 +
+ * vit_quant.py:141-142 (swin_quant.py:296-300) like ivit_mlp_fused.                                        */
+typedef struct ivit_mlp_plan_s *ivit_mlp_plan;
+int ivit_mlp_plan_create(ivit_handle h, ivit_linear_plan fc1, ivit_linear_plan fc2, ivit_mlp_plan *out);
+int ivit_mlp_plan_destroy(ivit_mlp_plan p);
+int ivit_mlp_fused_planned(ivit_handle h, ivit_mlp_plan p, const int8_t *x, const int8_t *gelu_table,
+                           ivit_dyadic dy_main, ivit_dyadic dy_res, const int16_t *residual, int16_t *out,
+                           int64_t M);
 /* PatchMerging's 2x2 gather (swin_quant.py:336-342): x [B,R,R,C] (in_bits 8 or 16) ->
  * int16 [B, (R/2)^2, 4C], channel blocks in the reference's torch.cat order.                  */
 int ivit_patch_merge_gather(ivit_handle h, const void *x, int in_bits, int B, int R, int C, int16_t *out);

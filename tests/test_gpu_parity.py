@@ -704,6 +704,49 @@ def test_mlp_fused_equals_unfused_chain(H, M):
     assert st == 3
 
 
+@pytest.mark.parametrize("M", [64, 1000, 64 * 300 + 17])
+def test_mlp_fused_planned_equals_unfused_chain(H, M):
+    """ivit_mlp_fused_planned (D = 384, hidden = 1536: weights streamed in fragment order, hidden tile in LDS) == the planned
+    fc1+requant -> GELU table -> fc2+requant+identity kernels it replaces; ragged last unit; repeated launches."""
+    rng = np.random.default_rng(M + 5)
+    C, HD = 384, 1536
+    x = dev(rng.integers(-128, 128, (M, C), dtype=np.int8))
+    w1 = dev(rng.integers(-128, 128, (HD, C), dtype=np.int8)); b1 = dev(rng.integers(-3000, 3000, HD).astype(np.int32))
+    w2 = dev(rng.integers(-128, 128, (C, HD), dtype=np.int8)); b2 = dev(rng.integers(-3000, 3000, C).astype(np.int32))
+    d1 = dev(iv.freeze.dyadic((10 ** rng.uniform(-5.6, -5.2, HD)).astype(np.float32), np.float32(0.012)))
+    d2 = dev(iv.freeze.dyadic((10 ** rng.uniform(-5.9, -5.5, C)).astype(np.float32), np.float32(2e-4)))
+    dm = iv.freeze.dyadic(np.float32(2e-4), np.float32(3.1e-4)); dr = iv.freeze.dyadic(np.float32(2.7e-4), np.float32(3.1e-4))
+    res = dev(rng.integers(-30000, 30000, (M, C)).astype(np.int16))
+    tab = torch.empty(65536, dtype=torch.int8, device="cuda")
+    H.call("ivit_shiftgelu_build_table", 0.03, dyv(iv.freeze.dyadic(np.float32(0.03 * 2.0 ** -7), np.float32(0.02))), P(tab))
+    p1, p2, mp = _P(), _P(), _P()
+    H.call("ivit_linear_plan_create", P(w1), P(b1), P(d1), HD, C, ctypes.byref(p1))
+    H.call("ivit_linear_plan_create", P(w2), P(b2), P(d2), C, HD, ctypes.byref(p2))
+    H.call("ivit_mlp_plan_create", p1, p2, ctypes.byref(mp))
+    try:
+        h8 = torch.empty(M, HD, dtype=torch.int8, device="cuda"); g8 = torch.empty_like(h8)
+        ref = torch.empty(M, C, dtype=torch.int16, device="cuda")
+        H.call("ivit_linear_i8_requant_planned", p1, P(x), 8, P(h8), M)
+        H.call("ivit_shiftgelu_requant_lut", P(h8), M, HD, P(tab), P(g8))
+        H.call("ivit_linear_i8_requant_residual_planned", p2, P(g8), dyv(dm), dyv(dr), P(res), P(ref), M)
+        hh = h8.cpu().numpy().astype(np.int32)
+        assert hh.max() == 127 and hh.min() == -128          # the hidden tensor saturates on both sides
+        for _ in range(3):
+            out = torch.full((M, C), -7, dtype=torch.int16, device="cuda")
+            H.call("ivit_mlp_fused_planned", mp, P(x), P(tab), dyv(dm), dyv(dr), P(res), P(out), M)
+            assert np.array_equal(out.cpu().numpy(), ref.cpu().numpy())
+        # multipliers outside the fast residual range are refused, not mis-computed
+        big = _lib.Dyadic(1024.0, 1.0)
+        assert H.lib.ivit_mlp_fused_planned(H.h, mp, P(x), P(tab), big, dyv(dr), P(res), P(out), M) == 3
+        # other shapes are refused at plan time
+        bad = _P()
+        assert H.lib.ivit_mlp_plan_create(H.h, p2, p1, ctypes.byref(bad)) == 3
+    finally:
+        H.lib.ivit_mlp_plan_destroy(mp)
+        H.lib.ivit_linear_plan_destroy(p1)
+        H.lib.ivit_linear_plan_destroy(p2)
+
+
 def test_normalize_quantize_u8_matches_torch_transform_chain():
     """N3 (device part): uint8 HWC -> ToTensor -> Normalize -> input QuantAct == the same chain in torch CPU
     fp32 (what torchvision's ToTensor / Normalize compute), for every pixel value and odd image sizes."""
