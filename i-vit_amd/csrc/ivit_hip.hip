@@ -579,8 +579,12 @@ int ivit_mlp_fused_planned(ivit_handle h, ivit_mlp_plan p, const int8_t *x, cons
     const void *fn = p->fma ? (const void *)mlp384_kernel<true> : (const void *)mlp384_kernel<false>;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_SMEM);
     if (e != hipSuccess) { snprintf(h->err, sizeof(h->err), "%s: attr: %s", __func__, hipGetErrorString(e)); return IVIT_ERR_HIP; }
-    const long long nunits = (M + MLP_BM - 1) / MLP_BM;
+    // one workgroup per CU.  64-token units round-robin unless cutting contiguous tile ranges into units of <= 5 tiles
+    // saves a whole round (a unit costs a pass over both weight matrices whatever its size)
+    const long long ntiles = (M + 15) / 16, nunits = (ntiles + MLP_TT - 2) / (MLP_TT - 1);
     const unsigned grid = (unsigned)(nunits < h->num_cu ? nunits : h->num_cu);
+    const long long rounds_fixed = (nunits + grid - 1) / grid, rounds_bal = (ntiles + (long long)MLP_TT * grid - 1) / ((long long)MLP_TT * grid);
+    a.balanced = rounds_bal < rounds_fixed;
     if (p->fma) mlp384_kernel<true><<<grid, MLP_THREADS, MLP_SMEM, h->stream>>>(a);
     else mlp384_kernel<false><<<grid, MLP_THREADS, MLP_SMEM, h->stream>>>(a);
     LAUNCH_CHECK(h);

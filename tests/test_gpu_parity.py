@@ -704,10 +704,11 @@ def test_mlp_fused_equals_unfused_chain(H, M):
     assert st == 3
 
 
-@pytest.mark.parametrize("M", [64, 1000, 64 * 300 + 17])
+@pytest.mark.parametrize("M", [64, 1000, 64 * 300 + 17, 25216, 16 * 256 * 3 + 5])
 def test_mlp_fused_planned_equals_unfused_chain(H, M):
     """ivit_mlp_fused_planned (D = 384, hidden = 1536: weights streamed in fragment order, hidden tile in LDS) == the planned
-    fc1+requant -> GELU table -> fc2+requant+identity kernels it replaces; ragged last unit; repeated launches."""
+    fc1+requant -> GELU table -> fc2+requant+identity kernels it replaces; ragged last tile, units of 1..5 token tiles
+    (25216 tokens = 6.2 tiles per workgroup: units of 3 and 4 tiles); repeated launches."""
     rng = np.random.default_rng(M + 5)
     C, HD = 384, 1536
     x = dev(rng.integers(-128, 128, (M, C), dtype=np.int8))

@@ -22,7 +22,7 @@ int main(int argc, char **argv) {
     hipMalloc(&x, hx.size()); hipMalloc(&w1, hw1.size()); hipMalloc(&w2, hw2.size()); hipMalloc(&tab, 65536);
     hipMalloc(&b1, MLP_HD * 4); hipMalloc(&b2, MLP_C * 4); hipMalloc(&c1, MLP_HD * 8); hipMalloc(&c2, MLP_C * 8);
     hipMalloc(&res, hres.size() * 2); hipMalloc(&out, hres.size() * 2); hipMalloc(&w1f, hw1.size()); hipMalloc(&w2f, hw2.size());
-    hipMalloc(&tr, 4 * MLP_WAVES * 8 * 8); hipMemset(tr, 0, 4 * MLP_WAVES * 8 * 8);
+    hipMalloc(&tr, (4 * MLP_WAVES * 8 + MLP_WAVES * 32) * 8); hipMemset(tr, 0, (4 * MLP_WAVES * 8 + MLP_WAVES * 32) * 8);
     hipMemcpy(x, hx.data(), hx.size(), hipMemcpyHostToDevice); hipMemcpy(w1, hw1.data(), hw1.size(), hipMemcpyHostToDevice);
     hipMemcpy(w2, hw2.data(), hw2.size(), hipMemcpyHostToDevice); hipMemcpy(tab, htab.data(), 65536, hipMemcpyHostToDevice);
     hipMemcpy(b1, hb1.data(), MLP_HD * 4, hipMemcpyHostToDevice); hipMemcpy(b2, hb2.data(), MLP_C * 4, hipMemcpyHostToDevice);
@@ -32,9 +32,9 @@ int main(int argc, char **argv) {
     mlp_swizzle_kernel<<<256, 256>>>(w2, MLP_C, MLP_HD, w2f);
     MlpArgs a;
     a.x = x; a.w1f = w1f; a.w2f = w2f; a.b1 = b1; a.b2 = b2; a.cq1 = c1; a.cq2 = c2; a.tab = tab; a.residual = res; a.out = out;
-    a.cm = 0.645; a.cr = 0.871; a.M = M; a.trace = tr;
+    a.cm = 0.645; a.cr = 0.871; a.M = M; a.trace = tr; a.balanced = argc > 2 ? atoi(argv[2]) : 1;
     hipFuncSetAttribute((const void *)mlp384_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_SMEM);
-    const long long nunits = (M + 63) / 64;
+    const long long nunits = ((M + 15) / 16 + MLP_TT - 2) / (MLP_TT - 1);
     const unsigned grid = (unsigned)(nunits < 256 ? nunits : 256);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
@@ -61,6 +61,16 @@ int main(int argc, char **argv) {
                 for (int w = 0; w < MLP_WAVES; ++w) printf(" %6lld", (long long)(h[(u * MLP_WAVES + w) * 8 + pt] - t0));
                 printf("\n");
             }
+        }
+    }
+    if (MLP_TRACE == 2) {
+        std::vector<unsigned long long> h(MLP_WAVES * 32);
+        hipMemcpy(h.data(), tr + 4 * MLP_WAVES * 8, h.size() * 8, hipMemcpyDeviceToHost);
+        printf("fc2 step durations (cycles), unit 2, per wave\n");
+        for (int w = 0; w < MLP_WAVES; ++w) {
+            printf("  wave %2d:", w);
+            for (int s2 = 1; s2 < 24; ++s2) printf(" %4lld", (long long)(h[w * 32 + s2] - h[w * 32 + s2 - 1]));
+            printf("\n");
         }
     }
     return 0;
