@@ -7,6 +7,7 @@
 #include <string.h>
 #include <new>
 #include <dlfcn.h>
+#include <mutex>
 #include "ivit_device.h"
 #include "ivit_elementwise.h"
 #include "ivit_layernorm.h"
@@ -24,9 +25,22 @@ struct ivit_ctx {
     char err[256];
 };
 
-// every entry point binds the calling thread to the handle's device first: one process may drive several GPUs
-// through several handles
-#define CHECK_H(h) do { if (!(h)) return IVIT_ERR_INVALID; if (hipSetDevice((h)->device) != hipSuccess) return IVIT_ERR_HIP; } while (0)
+// every entry point binds the calling thread to the handle's device for the duration of the call and puts the caller's
+// current device back on the way out: one process may drive several GPUs through several handles, and a torch (or any
+// other HIP) user of the same thread keeps allocating / launching where it was
+struct ivit_device_guard {
+    int prev = -1;
+    bool restore = false;
+    bool enter(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev == dev) return true;
+        if (hipSetDevice(dev) != hipSuccess) return false;
+        restore = prev >= 0;
+        return true;
+    }
+    ~ivit_device_guard() { if (restore) (void)hipSetDevice(prev); }
+};
+#define CHECK_H(h) if (!(h)) return IVIT_ERR_INVALID; ivit_device_guard ivit_dev_guard_; if (!ivit_dev_guard_.enter((h)->device)) return IVIT_ERR_HIP
 #define REQUIRE(h, cond, msg) do { if (!(cond)) { snprintf((h)->err, sizeof((h)->err), "%s: %s", __func__, msg); return IVIT_ERR_INVALID; } } while (0)
 #define LAUNCH_CHECK(h) do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { snprintf((h)->err, sizeof((h)->err), "%s: %s", __func__, hipGetErrorString(e_)); return IVIT_ERR_HIP; } } while (0)
 
@@ -76,10 +90,23 @@ int ivit_set_stream(ivit_handle h, void *hip_stream) {
 const char *ivit_last_error(ivit_handle h) { return h ? h->err : "null handle"; }
 
 // tuning / ablation switches are read once per process (thread-safe static initialisation at the call site)
-static int env_int(const char *name, int dflt) {
-    const char *e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
+// Experiment switches of the dispatch are COMPILE-TIME options (build a scratch library with -DIVIT_OPT_...=n and point
+// IVIT_LIB at it): a stray environment variable must not change which kernel a user of the library gets.
+#ifndef IVIT_OPT_GEMM3
+#define IVIT_OPT_GEMM3 7                // epilogues on the persistent pipelined kernels: 1 requant, 2 qkv scatter, 4 requant + residual
+#endif
+#ifndef IVIT_OPT_GEMM3_RES_MIN_N
+#define IVIT_OPT_GEMM3_RES_MIN_N 512    // residual flavour on the persistent kernel from this output width on
+#endif
+#ifndef IVIT_OPT_GEMM3_FMA
+#define IVIT_OPT_GEMM3_FMA (-1)         // -1: as the plan proves; 0 / 1: force the two-rounding / single-FMA requant (1 only where proven)
+#endif
+#ifndef IVIT_OPT_GEMM_BM
+#define IVIT_OPT_GEMM_BM 0              // 0: tile height by the occupancy estimate; 128 / 256: forced
+#endif
+#ifndef IVIT_OPT_ATTN_GENERIC
+#define IVIT_OPT_ATTN_GENERIC 0         // 1: run-time token count; 2: arithmetic Shiftmax even when tables are given
+#endif
 
 static inline int grid_for(ivit_handle h, long long work_items, int per_block) {
     long long g = (work_items + per_block - 1) / per_block;
@@ -147,8 +174,8 @@ static int launch_gemm(ivit_handle h, GemmArgs &a, int nb) {
 template <int EPI>
 static int launch_gemm2(ivit_handle h, GemmArgs &a) {
     a.tiles_n = (a.N + G2_BN - 1) / G2_BN;
-    static const int dbg = env_int("IVIT_GEMM_DBG", 0), force_bm = env_int("IVIT_GEMM_BM", 0);
-    a.dbg = dbg;
+    constexpr int force_bm = IVIT_OPT_GEMM_BM;
+    a.dbg = 0;
     // tile height: estimated time ~ ceil(tiles / resident slots) * rows per tile; 256-row tiles run
     // 2 per CU, 128-row tiles 3 per CU.  Ties go to the larger tile (better operand reuse).
     const long long t256 = (long long)((a.M + 255) / 256) * a.tiles_n, t128 = (long long)((a.M + 127) / 128) * a.tiles_n;
@@ -301,13 +328,12 @@ int ivit_constants_broadcast(ivit_handle h, void *device_blob, size_t bytes, int
     REQUIRE(h, device_blob && rccl_comm && bytes > 0 && root >= 0, "bad arguments");
     typedef int (*bcast_fn)(const void *, void *, size_t, int, int, void *, hipStream_t);
     static bcast_fn fn = nullptr;
-    static bool tried = false;
-    if (!tried) {
-        tried = true;
+    static std::once_flag once;
+    std::call_once(once, [] {
         void *lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
         if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
         if (lib) fn = (bcast_fn)dlsym(lib, "ncclBroadcast");
-    }
+    });
     if (!fn) { snprintf(h->err, sizeof(h->err), "ivit_constants_broadcast: librccl.so / ncclBroadcast not found"); return IVIT_ERR_UNSUPPORTED; }
     const int rc = fn(device_blob, device_blob, bytes, /* ncclUint8 */ 1, root, rccl_comm, h->stream);   // in place: one ring over xGMI
     if (rc != 0) { snprintf(h->err, sizeof(h->err), "ivit_constants_broadcast: ncclBroadcast returned %d", rc); return IVIT_ERR_HIP; }
@@ -351,6 +377,7 @@ struct ivit_linear_plan_s {
     double *cq;
     void *dummy;
     int pipelined_ok, single_fma_ok;
+    int device;                 // where `dev` lives: destroy / debug reads run there whatever the caller's current device is
 };
 
 extern "C" {
@@ -359,7 +386,6 @@ int ivit_linear_plan_create(ivit_handle h, const int8_t *w, const int32_t *bias,
                             ivit_linear_plan *out) {
     CHECK_H(h);
     REQUIRE(h, w && dy_ch && out && N > 0 && K > 0, "bad arguments");
-    if (hipSetDevice(h->device) != hipSuccess) return IVIT_ERR_HIP;
     const size_t cq_bytes = ((size_t)N * 8 + 255) & ~(size_t)255, b_bytes = ((size_t)N * 4 + 255) & ~(size_t)255;
     char *dev = nullptr;
     hipError_t e = hipMalloc((void **)&dev, cq_bytes + b_bytes + 256 + 1024 + 8192);
@@ -385,12 +411,15 @@ int ivit_linear_plan_create(ivit_handle h, const int8_t *w, const int32_t *bias,
     p->dummy = dev + cq_bytes + b_bytes + 256;
     p->pipelined_ok = !(host_bad & 1);
     p->single_fma_ok = !(host_bad & 2);
+    p->device = h->device;
     *out = p;
     return IVIT_OK;
 }
 
 int ivit_linear_plan_destroy(ivit_linear_plan p) {
     if (!p) return IVIT_ERR_INVALID;
+    ivit_device_guard g;
+    if (!g.enter(p->device)) return IVIT_ERR_HIP;
     (void)hipFree(p->dev);
     delete p;
     return IVIT_OK;
@@ -398,6 +427,8 @@ int ivit_linear_plan_destroy(ivit_linear_plan p) {
 
 int ivit_debug_plan_scratch(ivit_linear_plan p, void *host_dst, int nbytes) {
     if (!p || !host_dst || nbytes <= 0 || nbytes > 8192) return IVIT_ERR_INVALID;
+    ivit_device_guard g;
+    if (!g.enter(p->device)) return IVIT_ERR_HIP;
     if (hipDeviceSynchronize() != hipSuccess) return IVIT_ERR_HIP;
     return hipMemcpy(host_dst, (char *)p->dummy + 1024, (size_t)nbytes, hipMemcpyDeviceToHost) == hipSuccess ? IVIT_OK : IVIT_ERR_HIP;
 }
@@ -415,10 +446,10 @@ int ivit_linear_plan_query(ivit_linear_plan p, int *pipelined_ok, int *single_fm
 // IVIT_GEMM3: bit mask of the epilogues that run on the persistent pipelined kernels — 1 requant (8/16-bit), 2 qkv
 // scatter, 4 requant + residual; the others stay on the launch-per-tile kernels (A/B and fallback).
 static inline bool use_gemm3(const ivit_linear_plan_s *pl, const GemmArgs &a, int epi_bit) {
-    static const int on = env_int("IVIT_GEMM3", 7);
+    constexpr int on = IVIT_OPT_GEMM3;
     // the residual flavour on a narrow output (N = 384: three channel tiles per 256-token panel, 77 % balance, and its
     // 32 resident residual registers) measured no better in-model than the launch-per-tile kernel: N >= 512 only
-    static const int res_min_n = env_int("IVIT_GEMM3_RES_MIN_N", 512);
+    constexpr int res_min_n = IVIT_OPT_GEMM3_RES_MIN_N;
     if (epi_bit == 4 && a.N < res_min_n) return false;
     return (on & epi_bit) && pl->pipelined_ok && (a.K % 64) == 0 && a.K >= 320 && (a.N % 16) == 0 && (a.ldc % 16) == 0 &&
            (a.lda % 16) == 0 && (a.ldb % 16) == 0 && a.M >= 128;
@@ -430,9 +461,9 @@ static int launch_gemm3(ivit_handle h, const ivit_linear_plan_s *pl, GemmArgs &a
     a.cq = pl->cq;
     a.bias = pl->bias_eff;
     a.dummy = pl->dummy;
-    static const int force_fma = env_int("IVIT_GEMM3_FMA", -1), wg_per_cu = env_int("IVIT_GEMM3_WGS", 2);
-    static const int dbg3 = env_int("IVIT_GEMM3_DBG", 0), astat_on = env_int("IVIT_GEMM3_ASTAT", 1);
-    a.dbg = dbg3;
+    constexpr int force_fma = IVIT_OPT_GEMM3_FMA, wg_per_cu = 2;
+    constexpr bool astat_on = true;
+    a.dbg = 0;
     const bool fma = force_fma >= 0 ? (force_fma != 0 && pl->single_fma_ok) : (pl->single_fma_ok != 0);
     // gemm_as_kernel: K = n * 384; the qkv scatter additionally needs whole units inside one of q / k / v and whole
     // 32-channel groups inside one head.  Its operand offsets are 32-bit and its epilogue goes through buffer
@@ -447,13 +478,6 @@ static int launch_gemm3(ivit_handle h, const ivit_linear_plan_s *pl, GemmArgs &a
         const long long nunits = (long long)((a.M + 255) / 256) * a.tiles_n;
         long long grid = h->num_cu;
         if (grid > nunits) grid = nunits;
-        // experiment switch: the fewest workgroups with the same makespan (units per workgroup = ceil(nunits / CUs)), so
-        // that the CUs left over run the other batch slices' kernels.  Measured neutral (3.58-3.61 ms either way): off.
-        static const int trim = env_int("IVIT_GEMM3_TRIM_GRID", 0);
-        if (trim) {
-            const long long upw = (nunits + grid - 1) / grid;
-            grid = (nunits + upw - 1) / upw;
-        }
         const dim3 g((unsigned)grid);
         if (a.K == GA_BK * GA_NK) {
             if (fma) gemm_as_kernel<EPI, false, true><<<g, 512, 0, h->stream>>>(a);
@@ -559,6 +583,8 @@ int ivit_mlp_plan_create(ivit_handle h, ivit_linear_plan fc1, ivit_linear_plan f
 
 int ivit_mlp_plan_destroy(ivit_mlp_plan p) {
     if (!p) return IVIT_ERR_INVALID;
+    ivit_device_guard g;
+    if (!g.enter(p->device)) return IVIT_ERR_HIP;
     (void)hipFree(p->w1f);
     delete p;
     return IVIT_OK;
@@ -611,8 +637,7 @@ template <int NB>
 static int launch_attn(ivit_handle h, const AttnArgs &a, int BH) {
     const double cq = a.dy_qk.m * a.dy_qk.r, cp = a.dy_pv.m * a.dy_pv.r;
     const bool fast = (cq < 512.0 && cq > -512.0 && cp < 512.0 && cp > -512.0);
-    // IVIT_ATTN_DYNAMIC_T=1 / IVIT_ATTN_NO_LUT=1: generic forms (A/B, tests)
-    static const int dyn_t = env_int("IVIT_ATTN_DYNAMIC_T", 0), no_lut = env_int("IVIT_ATTN_NO_LUT", 0);
+    constexpr bool dyn_t = (IVIT_OPT_ATTN_GENERIC & 1) != 0, no_lut = (IVIT_OPT_ATTN_GENERIC & 2) != 0;
     const bool lut = a.aq && a.et && a.cls && !no_lut;
     if (fast && !dyn_t) {
         if (NB == 4 && a.T == 197) return lut ? launch_attn2<NB, true, 197, true>(h, a, BH) : launch_attn2<NB, true, 197>(h, a, BH);
@@ -770,7 +795,7 @@ int ivit_shiftgelu_requant_lut(ivit_handle h, const int8_t *x, int64_t rows, int
     REQUIRE(h, x && out8 && table && rows > 0 && C > 0, "bad arguments");
     REQUIRE(h, (C % 16) == 0, "C must be a multiple of 16");
     // half a wavefront per row, row in registers: ITER = ceil(C / 512) chunks of 16 bytes per lane
-    static const int lut_old = env_int("IVIT_GELU_OLD", 0);
+    constexpr bool lut_old = false;
     const int iter = (C / 16 + 31) / 32;
     const unsigned grid2 = (unsigned)((rows + 7) / 8);
     if (lut_old || iter > 6) shiftgelu_lut_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, h->stream>>>(x, rows, C, table, out8);

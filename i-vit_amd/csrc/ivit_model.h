@@ -318,7 +318,9 @@ struct ivit_swin_s {
     std::vector<ivit_swin_merge> merges;
     int grid, nblocks;
     ivit_dyadic dy_qact1_host;        // host copy of prm.dy_qact1[0]
-    bool fused_mlp;                   // IVIT_SWIN_FUSED_MLP=0 disables the stage-0 fused MLP (A/B, tests)
+    bool fused_mlp;                   // stage-0 Mlp in one kernel (ivit_mlp_fused)
+    std::vector<ivit_linear_plan> mlp_lin;   // per block: fc1, fc2 plans of the C = 384 stage (null elsewhere)
+    std::vector<ivit_mlp_plan> mlp_plans;    // per block: fused Mlp plan (C = 384, hidden 1536) or null
     int8_t *gelu_tab;                 // [nblocks][65536]
     int max_slices;
     std::vector<ivit_handle> slice_h;
@@ -390,9 +392,13 @@ int swin_run_slice(const ivit_swin_s *m, ivit_handle h, const int8_t *images, in
             RUN(ivit_linear_i8_requant_residual(h, ctx, b.proj.w, b.proj.b, b.proj.dy, b.res1_main, b.res1_res, x, y, (int)M, C, C));
             { int16_t *t = x; x = y; y = t; }
             RUN(swin_ln(m, h, x, M, C, b.s_mid, b.n2, L, li == 0, a8));
+            const bool mlp384 = m->mlp_plans[bi] && fabs(b.res2_main.m * b.res2_main.r) < RQ_FAST_CLIM &&
+                                fabs(b.res2_res.m * b.res2_res.r) < RQ_FAST_CLIM;
             if (C == 96 && c.mlp_ratio == 4 && m->fused_mlp) {     // narrow stage: hidden tensor stays in LDS
                 RUN(ivit_mlp_fused(h, a8, b.fc1.w, b.fc1.b, b.fc1.dy, m->gelu_tab + (size_t)bi * 65536, b.fc2.w, b.fc2.b,
                                    b.fc2.dy, b.res2_main, b.res2_res, x, y, M, C, 4 * C));
+            } else if (mlp384) {                                    // C = 384 stage: weights streamed, hidden tile in LDS
+                RUN(ivit_mlp_fused_planned(h, m->mlp_plans[bi], a8, m->gelu_tab + (size_t)bi * 65536, b.res2_main, b.res2_res, x, y, M));
             } else {
                 RUN(ivit_linear_i8_requant(h, a8, b.fc1.w, b.fc1.b, b.fc1.dy, 8, h8, (int)M, c.mlp_ratio * C, C));
                 RUN(ivit_shiftgelu_requant_lut(h, h8, M, c.mlp_ratio * C, m->gelu_tab + (size_t)bi * 65536, g8));
@@ -430,6 +436,8 @@ int ivit_swin_destroy(ivit_swin m) {
     for (auto st : m->streams) (void)hipStreamDestroy(st);
     if (m->fork) (void)hipEventDestroy(m->fork);
     if (m->gelu_tab) (void)hipFree(m->gelu_tab);
+    for (auto mp : m->mlp_plans) if (mp) (void)ivit_mlp_plan_destroy(mp);
+    for (auto pl : m->mlp_lin) if (pl) (void)ivit_linear_plan_destroy(pl);
     delete m;
     return IVIT_OK;
 }
@@ -460,7 +468,7 @@ int ivit_swin_create(ivit_handle h, const ivit_swin_config *cfg, const ivit_swin
     m->blocks.assign(params->blocks_host, params->blocks_host + nb);
     if (cfg->num_layers > 1) m->merges.assign(params->merges_host, params->merges_host + cfg->num_layers - 1);
     m->grid = grid; m->nblocks = nb; m->gelu_tab = nullptr; m->max_slices = max_slices; m->fork = nullptr;
-    m->fused_mlp = env_int("IVIT_SWIN_FUSED_MLP", 1) != 0;
+    m->fused_mlp = true;
     if (hipMemcpy(&m->dy_qact1_host, params->dy_qact1, sizeof(ivit_dyadic), hipMemcpyDeviceToHost) != hipSuccess) {
         snprintf(h->err, sizeof(h->err), "ivit_swin_create: cannot read dy_qact1");
         delete m;
@@ -474,6 +482,24 @@ int ivit_swin_create(ivit_handle h, const ivit_swin_config *cfg, const ivit_swin
     for (int i = 0; i < nb; ++i) {
         int rc = ivit_shiftgelu_build_table(h, m->blocks[i].s_gelu, m->blocks[i].dy_gelu, m->gelu_tab + (size_t)i * 65536);
         if (rc != IVIT_OK) { ivit_swin_destroy(m); return rc; }
+    }
+    {   // fused Mlp plans for the C = 384 stage (hidden 1536)
+        int bi = 0;
+        for (int li = 0; li < cfg->num_layers; ++li)
+            for (int bj = 0; bj < cfg->depths[li]; ++bj, ++bi) {
+                const int C = cfg->embed_dim << li;
+                ivit_linear_plan p1 = nullptr, p2 = nullptr;
+                ivit_mlp_plan mp = nullptr;
+                const ivit_swin_block &b = m->blocks[bi];
+                if (C == MLP_C && cfg->mlp_ratio * C == MLP_HD &&
+                    ivit_linear_plan_create(h, b.fc1.w, b.fc1.b, b.fc1.dy, MLP_HD, MLP_C, &p1) == IVIT_OK &&
+                    ivit_linear_plan_create(h, b.fc2.w, b.fc2.b, b.fc2.dy, MLP_C, MLP_HD, &p2) == IVIT_OK) {
+                    if (ivit_mlp_plan_create(h, p1, p2, &mp) != IVIT_OK) mp = nullptr;
+                }
+                m->mlp_lin.push_back(p1);
+                m->mlp_lin.push_back(p2);
+                m->mlp_plans.push_back(mp);
+            }
     }
     if (max_slices > 1) {
         bool ok = hipEventCreateWithFlags(&m->fork, hipEventDisableTiming) == hipSuccess;

@@ -85,16 +85,27 @@ class ViTEngine:
             self.h.call("ivit_shiftgelu_build_table", self.f32[p + "mlp.s_gelu"], _dy(self.host[p + "mlp.dy_gelu"]),
                         _P(self.gelu_tab[i].data_ptr()))
 
+        # frozen-QuantLinear plans for forward_ops, built HERE (plan creation allocates and synchronises: not something
+        # to do lazily inside a timed / captured forward); use_plans = False issues the unplanned kernels instead
+        self.use_plans = True
+        self.use_fused_mlp = True       # forward_ops: ivit_mlp_fused_planned where a fused plan exists (D = 384)
         self._plans = {}
+        self._mlp_plans = {}
+        D, Hd = cfg.embed_dim, cfg.hidden_dim
+        for i in range(cfg.depth):
+            p = f"blocks.{i}."
+            for name, N, K in ((p + "attn.qkv", 3 * D, D), (p + "attn.proj", D, D), (p + "mlp.fc1", Hd, D), (p + "mlp.fc2", D, Hd)):
+                self._plans[name] = self.h.linear_plan(self.ptr(name + ".w"), self.ptr(name + ".b"), self.ptr(name + ".dy"), N, K)
+            mp = _P()
+            if self.h.lib.ivit_mlp_plan_create(self.h.h, self._plans[p + "mlp.fc1"].p, self._plans[p + "mlp.fc2"].p, ctypes.byref(mp)) == 0:
+                self._mlp_plans[i] = mp
         self._build_native()
 
     MAX_SLICES = 8
 
-    def plan(self, prefix, N, K):
-        """frozen-QuantLinear plan (ivit_linear_plan_create) of the layer `prefix` — built once, used by forward_ops;
-        the native runner holds its own."""
-        if prefix not in self._plans:
-            self._plans[prefix] = self.h.linear_plan(self.ptr(prefix + ".w"), self.ptr(prefix + ".b"), self.ptr(prefix + ".dy"), N, K)
+    def plan(self, prefix):
+        """frozen-QuantLinear plan (ivit_linear_plan_create) of the layer `prefix`, built in __init__; the native runner
+        holds its own."""
         return self._plans[prefix].p
 
     def _build_native(self):
@@ -137,6 +148,9 @@ class ViTEngine:
             if getattr(self, "model", None):
                 self.h.lib.ivit_vit_destroy(self.model)
                 self.model = None
+            for mp in getattr(self, "_mlp_plans", {}).values():
+                self.h.lib.ivit_mlp_plan_destroy(mp)
+            self._mlp_plans = {}
             for pl in getattr(self, "_plans", {}).values():
                 pl.close()
         except Exception:
@@ -144,8 +158,12 @@ class ViTEngine:
 
     def _native_buffers(self, B, nslices):
         key = (B, nslices)
-        if key not in self._native_ws and len(self._native_ws) >= 4:
-            self._native_ws.pop(next(iter(self._native_ws)))          # bounded: at most 4 (batch, slices) shapes resident
+        if key not in self._native_ws:
+            # bounded: at most 4 (batch, slices) shapes that no captured graph refers to stay resident.  A graph has its
+            # workspace pointer baked in: those entries are pinned (self._graph_keys) and never evicted
+            free = [k for k in self._native_ws if k not in getattr(self, "_graph_keys", set())]
+            if len(free) >= 4:
+                self._native_ws.pop(free[0])
         if key not in self._native_ws:
             n = ctypes.c_size_t()
             self.h._check(self.h.lib.ivit_vit_workspace_bytes(self.model, B, nslices, ctypes.byref(n)), "ivit_vit_workspace_bytes")
@@ -189,10 +207,13 @@ class ViTEngine:
         g = _P()
         self.h._check(self.h.lib.ivit_vit_graph_create(self.model, _P(images.data_ptr()), B, nslices, _P(ws.data_ptr()),
                                                        ws.numel(), _P(logits.data_ptr()), ctypes.byref(g)), "ivit_vit_graph_create")
-        self._graphs = getattr(self, "_graphs", []) + [g]
+        # the graph replays on `ws` / `logits` / `images`: all three live as long as the replay closure does, and the
+        # workspace entry is pinned against eviction
+        self._graphs = getattr(self, "_graphs", []) + [(g, ws, logits, images)]
+        self._graph_keys = getattr(self, "_graph_keys", set()) | {(B, nslices)}
         lib, gs, dev = self.h.lib, self._gstream, self.device
 
-        def replay():
+        def replay(_keep=(ws, logits, images)):
             cur = torch.cuda.current_stream(dev)
             gs.wait_stream(cur)
             self.h.set_stream(gs.cuda_stream)
@@ -266,8 +287,12 @@ class ViTEngine:
             p = f"blocks.{i}."
             call("ivit_layernorm_requant", P(x), M, D, D, f32[p + "ln1.s"], self.ptr(p + "norm1.bias_int"),
                  self.ptr(p + "norm1.sc"), self.ptr(p + "norm1.dy"), P(ws["a8"]))
-            call("ivit_linear_i8_qkv_planned", self.plan(p + "attn.qkv", 3 * D, D), P(ws["a8"]), P(ws["q"]), P(ws["k"]),
-                 P(ws["vt"]), B, T, H, dh, ld)
+            if self.use_plans:
+                call("ivit_linear_i8_qkv_planned", self.plan(p + "attn.qkv"), P(ws["a8"]), P(ws["q"]), P(ws["k"]),
+                     P(ws["vt"]), B, T, H, dh, ld)
+            else:
+                call("ivit_linear_i8_qkv", P(ws["a8"]), self.ptr(p + "attn.qkv.w"), self.ptr(p + "attn.qkv.b"),
+                     self.ptr(p + "attn.qkv.dy"), P(ws["q"]), P(ws["k"]), P(ws["vt"]), B, T, H, dh, ld)
             if self.fused_attention:
                 if p + "attn.exp_meta" in hc and self.use_exp_tables:
                     meta = hc[p + "attn.exp_meta"]
@@ -284,15 +309,31 @@ class ViTEngine:
                 call("ivit_shiftmax", P(ws["s8"]), B * H * T, T, ld, f32[p + "attn.s_softmax"], 16, P(ws["p16"]), ld)
                 call("ivit_attn_pv_requant", P(ws["p16"]), P(ws["vt"]), _dy(hc[p + "attn.dy_pv"]), P(ws["ctx8"]),
                      B, H, T, dh, ld, ld)
-            call("ivit_linear_i8_requant_residual_planned", self.plan(p + "attn.proj", D, D), P(ws["ctx8"]),
-                 _dy(hc[p + "res1.dy_main"]), _dy(hc[p + "res1.dy_res"]), P(x), P(y), M)
+            if self.use_plans:
+                call("ivit_linear_i8_requant_residual_planned", self.plan(p + "attn.proj"), P(ws["ctx8"]),
+                     _dy(hc[p + "res1.dy_main"]), _dy(hc[p + "res1.dy_res"]), P(x), P(y), M)
+            else:
+                call("ivit_linear_i8_requant_residual", P(ws["ctx8"]), self.ptr(p + "attn.proj.w"), self.ptr(p + "attn.proj.b"),
+                     self.ptr(p + "attn.proj.dy"), _dy(hc[p + "res1.dy_main"]), _dy(hc[p + "res1.dy_res"]), P(x), P(y), M, D, D)
             x, y = y, x
             call("ivit_layernorm_requant", P(x), M, D, D, f32[p + "ln2.s"], self.ptr(p + "norm2.bias_int"),
                  self.ptr(p + "norm2.sc"), self.ptr(p + "norm2.dy"), P(ws["a8"]))
-            call("ivit_linear_i8_requant_planned", self.plan(p + "mlp.fc1", Hd, D), P(ws["a8"]), 8, P(ws["h8"]), M)
-            call("ivit_shiftgelu_requant_lut", P(ws["h8"]), M, Hd, _P(self.gelu_tab[i].data_ptr()), P(ws["g8"]))
-            call("ivit_linear_i8_requant_residual_planned", self.plan(p + "mlp.fc2", D, Hd), P(ws["g8"]),
-                 _dy(hc[p + "res2.dy_main"]), _dy(hc[p + "res2.dy_res"]), P(x), P(y), M)
+            dm, dr = hc[p + "res2.dy_main"], hc[p + "res2.dy_res"]
+            fused = (self.use_plans and self.use_fused_mlp and i in self._mlp_plans
+                     and abs(dm[0, 0] * dm[0, 1]) < 512.0 and abs(dr[0, 0] * dr[0, 1]) < 512.0)
+            if fused:       # the runner's choice (csrc/ivit_model.h): hidden tensor never in HBM
+                call("ivit_mlp_fused_planned", self._mlp_plans[i], P(ws["a8"]), _P(self.gelu_tab[i].data_ptr()), _dy(dm), _dy(dr),
+                     P(x), P(y), M)
+            elif self.use_plans:
+                call("ivit_linear_i8_requant_planned", self.plan(p + "mlp.fc1"), P(ws["a8"]), 8, P(ws["h8"]), M)
+                call("ivit_shiftgelu_requant_lut", P(ws["h8"]), M, Hd, _P(self.gelu_tab[i].data_ptr()), P(ws["g8"]))
+                call("ivit_linear_i8_requant_residual_planned", self.plan(p + "mlp.fc2"), P(ws["g8"]), _dy(dm), _dy(dr), P(x), P(y), M)
+            else:
+                call("ivit_linear_i8_requant", P(ws["a8"]), self.ptr(p + "mlp.fc1.w"), self.ptr(p + "mlp.fc1.b"),
+                     self.ptr(p + "mlp.fc1.dy"), 8, P(ws["h8"]), M, Hd, D)
+                call("ivit_shiftgelu_requant_lut", P(ws["h8"]), M, Hd, _P(self.gelu_tab[i].data_ptr()), P(ws["g8"]))
+                call("ivit_linear_i8_requant_residual", P(ws["g8"]), self.ptr(p + "mlp.fc2.w"), self.ptr(p + "mlp.fc2.b"),
+                     self.ptr(p + "mlp.fc2.dy"), _dy(dm), _dy(dr), P(x), P(y), M, D, Hd)
             x, y = y, x
         # final norm on the class-token rows only (row stride T*D)
         call("ivit_layernorm_requant", P(x), B, D, T * D, f32["ln.s"], self.ptr("norm.bias_int"),

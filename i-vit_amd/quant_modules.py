@@ -98,8 +98,9 @@ def _scale_t(scale, x, channel_dim=-1):
 
 def from_fake(x, scale, dtype, lo, hi, what, channel_dim=-1):
     """fake-quant fp32 X = fl(Q*s) -> Q with the reference's rne(fl(X / s)); refuses off-grid or out-of-range input"""
-    q = torch.round(x.float() / _scale_t(scale, x, channel_dim))
-    bad = (q - x.float() / _scale_t(scale, x, channel_dim)).abs().max().item() if x.numel() else 0.0
+    quo = x.float() / _scale_t(scale, x, channel_dim)
+    q = torch.round(quo)
+    bad = (q - quo).abs().max().item() if x.numel() else 0.0
     if bad > 0.05:
         raise ValueError(f"{what}: input is not a fake-quant tensor of the given scale (|x/s - rne(x/s)| up to {bad:.3f}); "
                          "non-integer products must be folded into the scale or passed separately (e.g. IntSoftmax mask=)")
@@ -302,7 +303,15 @@ class QuantAct(nn.Module):
         if fake:
             # the reference's own first step, z = rne(fl(X / s_pre)) in fp32 (quant_utils.py:220): it can exceed int32 after
             # I-LayerNorm, so it stays an integer-valued fp32 tensor for the fp64 requant kernel
-            x = torch.round(x.float() / _scale_t(s_pre, x, cdim)).as_subclass(IntValued)
+            quo = x.float() / _scale_t(s_pre, x, cdim)
+            # A plain fp32 tensor is taken as the reference's fake-quant X = Q * s_pre.  An integer-valued tensor that lost
+            # its IntValued marker on the way (.numpy() / .data / an op outside __torch_function__) would be divided by the
+            # scale a second time: quotients no operator of the path can produce (the I-LayerNorm output, the largest, stays
+            # below 2^40) together with all-integer values are that case — refuse instead of returning other numbers
+            if quo.numel() and quo.abs().max().item() >= 2.0 ** 44 and bool((x.float() == torch.round(x.float())).all()):
+                raise ValueError("QuantAct: integer-valued fp32 input without the IntValued marker (x / s_pre reaches "
+                                 f"{quo.abs().max().item():.3g}); pass integers as an int dtype or re-wrap with IntValued")
+            x = torch.round(quo).as_subclass(IntValued)
             if identity is not None:
                 identity = from_fake(identity, identity_scaling_factor, torch.int32, -2 ** 31, 2 ** 31 - 1, "QuantAct identity")
         if conv_layout:

@@ -353,10 +353,10 @@ class SwinEngine:
         g = _P()
         self.h._check(self.h.lib.ivit_swin_graph_create(self.model, _P(images.data_ptr()), B, nslices, _P(ws.data_ptr()),
                                                         ws.numel(), _P(logits.data_ptr()), ctypes.byref(g)), "ivit_swin_graph_create")
-        self._graphs = getattr(self, "_graphs", []) + [g]
+        self._graphs = getattr(self, "_graphs", []) + [(g, ws, logits, images)]      # the graph's buffers live as long as it does
         lib, gs, dev = self.h.lib, self._gstream, self.device
 
-        def replay():
+        def replay(_keep=(ws, logits, images)):
             cur = torch.cuda.current_stream(dev)
             gs.wait_stream(cur)
             self.h.set_stream(gs.cuda_stream)

@@ -151,8 +151,9 @@ class VisionTransformer(nn.Module):
             s = self.qact_input.act_scaling_factor
             x = to_fake(x, s)
         else:
-            self.qact_input.fake_quant_input = True
-            x, s = self.qact_input(x)
+            # per call, not module state: a later fake_quant = False forward must get integers from qact_input again
+            q, s = self.qact_input(x)
+            x = q if q.is_floating_point() else to_fake(q, s)
         x, s = self.patch_embed(x, s)
         cls_tokens = self.cls_token.to(x.device).expand(B, -1, -1)     # a float: rounded inside qact1 like in the reference
         x = torch.cat((cls_tokens, x), dim=1)

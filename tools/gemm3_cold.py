@@ -1,6 +1,7 @@
 """GPU: the planned residual GEMM on the fc2 / proj shapes with HOT operands (back-to-back launches over the same buffers)
 and COLD ones (a 1 GB fill between launches evicts L2 and the Infinity Cache), timed per launch with events.
-IVIT_GEMM3=0 selects the launch-per-tile kernels, IVIT_GEMM3_RES_MIN_N=0 the persistent residual flavour."""
+The dispatch switches are compile-time now: build a scratch library with -DIVIT_OPT_GEMM3=0 (launch-per-tile kernels) or
+-DIVIT_OPT_GEMM3_RES_MIN_N=0 (persistent residual flavour) and point IVIT_LIB at it."""
 import ctypes, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
