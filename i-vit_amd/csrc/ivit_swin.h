@@ -144,11 +144,11 @@ __global__ __launch_bounds__(256) void layernorm_tokenorder_kernel(const XT *__r
     double *cC = reinterpret_cast<double *>(rF + LNT_ROWS + ((LNT_ROWS * LD + 3 * C + 2 * LNT_ROWS) & 1));   // 8-byte aligned
     const int tid = threadIdx.x;
     const long long row0 = (long long)blockIdx.x * LNT_ROWS;
-    const RcpC sr = rcp_prepare(s);
+    const float ys = rcp_rn(s);            // requotients by product + exact residual + one correction (ivit_layernorm.h)
     for (int c = tid; c < C; c += 256) {
         const float scv = sc[c];
         cSc[c] = scv;
-        cY[c] = rcp_prepare(scv).y;
+        cY[c] = rcp_rn(scv);
         cB[c] = bias_int[c];
         if (OUTM != 0) cC[c] = dy[c].m * dy[c].r;
     }
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void layernorm_tokenorder_kernel(const XT *__r
     for (int e = tid; e < total; e += 256) {
         const int r = e / C, c = e - r * C;
         const long long gr = row0 + r;
-        tile[r * LD + c] = gr < rows ? requotient_c((float)x[gr * C + c], sr) : 0.f;
+        tile[r * LD + c] = gr < rows ? requotient_m((float)x[gr * C + c], s, ys) : 0.f;
     }
     __syncthreads();
     if (tid < LNT_ROWS) {
@@ -188,10 +188,7 @@ __global__ __launch_bounds__(256) void layernorm_tokenorder_kernel(const XT *__r
         const float y = tile[r * LD + c] - rMean[r];
         const float yi = floorf((y * rF[r]) * 0.5f);
         const float o = yi + cB[c];
-        RcpC rc;
-        rc.d = cSc[c];
-        rc.y = cY[c];
-        const float zv = rintf(lean_div(o * rc.d, rc));
+        const float zv = rintf(requotient_m(o, cSc[c], cY[c]));
         if (OUT8) {
             reinterpret_cast<int8_t *>(out)[gr * C + c] = (int8_t)rq_c((double)zv, cC[c], -128, 127);
         } else if (OUTM == 2) {

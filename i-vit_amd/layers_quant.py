@@ -68,6 +68,6 @@ class PatchEmbed(nn.Module):
         s = s.reshape(-1)
         if self.norm_layer:
             x, s = self.qact_before_norm(x, s)
-            x, s = self.norm(x.to(torch.int16), s)
+            x, s = self.norm(x if x.is_floating_point() else x.to(torch.int16), s)     # fake-quant fp32 stays as it is
         x, s = self.qact(x, s)
         return x, s

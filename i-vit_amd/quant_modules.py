@@ -312,7 +312,7 @@ class QuantAct(nn.Module):
                 raise ValueError("QuantAct: integer-valued fp32 input without the IntValued marker (x / s_pre reaches "
                                  f"{quo.abs().max().item():.3g}); pass integers as an int dtype or re-wrap with IntValued")
             x = torch.round(quo).as_subclass(IntValued)
-            if identity is not None:
+            if identity is not None and _is_fake(identity):     # an integer identity (e.g. a quantised parameter table) stays
                 identity = from_fake(identity, identity_scaling_factor, torch.int32, -2 ** 31, 2 ** 31 - 1, "QuantAct identity")
         if conv_layout:
             x = x.permute(0, 2, 3, 1).contiguous()
@@ -569,7 +569,20 @@ class IntSoftmax(nn.Module):
         s = np.float32(_f32(scaling_factor)[0])
         fake = _is_fake(x)
         if fake:
-            x = from_fake(x, s, torch.int8, -128, 127, "IntSoftmax")
+            if mask is None and 128.0 * float(s) < 50.0 and x.numel() and x.min().item() < -50.0:
+                # The reference's Swin block adds its float mask to the fake-quant logits BEFORE this module
+                # (swin_quant.py:151-156: attn + mask, mask in {0, -100.0}), so a caller running the reference's own model
+                # code hands over X = fl(fl(Q*s) - 100) on the masked entries: off the grid of s, but an integer-domain
+                # side input in disguise.  On-grid values stay within 128 s < 50, so x < -50 identifies the masked
+                # entries; Q comes back from fl(x + 100) (the lost low bits are far below half a grid step), and the mask
+                # goes to the kernel as the side input it is — one window per leading row block (nW = rows / n, H = 1).
+                mk_full = torch.where(x < -50.0, torch.full_like(x, -100.0), torch.zeros_like(x)).float()
+                x = from_fake((x.float() - mk_full), s, torch.int8, -128, 127, "IntSoftmax (masked logits)")
+                mask, num_heads = mk_full.reshape(-1, x.shape[-1], x.shape[-1]), 1
+                if x.shape[-2] != x.shape[-1]:
+                    raise ValueError("IntSoftmax: masked fake-quant logits must be [..., n, n]")
+            else:
+                x = from_fake(x, s, torch.int8, -128, 127, "IntSoftmax")
         n = x.shape[-1]
         xc = x.contiguous()
         out = torch.empty(x.shape, dtype=torch.int16, device=x.device)    # uint16 payload

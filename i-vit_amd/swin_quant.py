@@ -17,7 +17,7 @@ import torch.nn as nn
 from . import freeze as fz
 from .layers_quant import PatchEmbed, Mlp, DropPath, to_2tuple
 from .quant_modules import (QuantLinear, QuantAct, IntLayerNorm, IntSoftmax, IntGELU, QuantMatMul, _f32, _ptr,
-                            _dyv, handle)
+                            _dyv, handle, _is_fake, to_fake)
 from .synth import SwinConfig
 
 __all__ = ["swin_tiny_patch4_window7_224", "swin_small_patch4_window7_224", "swin_base_patch4_window7_224",
@@ -71,13 +71,27 @@ class WindowAttention(nn.Module):
         qkv = x.reshape(B_, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4)
         q, k, v = qkv[0], qkv[1], qkv[2]
         attn, s = self.matmul_1(q, s1, k.transpose(-2, -1), s1)
-        # attn * scale, scale * scale (swin_quant.py:133-134): integers unchanged, fp32 scale product
+        # attn * scale, scale * scale (swin_quant.py:133-134): integers unchanged, fp32 scale product; a fake-quant fp32
+        # `attn` (the reference's convention) is scaled exactly like the reference scales it
+        fake = _is_fake(attn)
+        if fake:
+            attn = attn * self.scale
         s = torch.from_numpy((_f32(s) * np.float32(self.scale)).astype(np.float32))
         attn, s = self.qact_attn1(attn, s)
         tab_q, s_tab = self.qact_table(self.relative_position_bias_table.detach().to(x.device))
+        if fake and not _is_fake(tab_q):
+            tab_q = to_fake(tab_q, s_tab)
         bias = tab_q[self.relative_position_index.view(-1).to(x.device)].view(N, N, -1).permute(2, 0, 1).contiguous()
         attn, s = self.qact2(attn, s, bias.unsqueeze(0), s_tab)
-        attn, s = self.log_int_softmax(attn, s, mask=mask, num_heads=self.num_heads)
+        if fake and mask is not None:
+            # the reference's own statements (swin_quant.py:151-156): the float mask is ADDED to the fake-quant logits and
+            # Shiftmax gets the sum — IntSoftmax recognises the masked entries and treats the mask as the side input it is
+            nW = mask.shape[0]
+            attn = attn.view(B_ // nW, nW, self.num_heads, N, N) + mask.to(attn.device).unsqueeze(1).unsqueeze(0)
+            attn = attn.view(-1, self.num_heads, N, N)
+            attn, s = self.log_int_softmax(attn, s)
+        else:
+            attn, s = self.log_int_softmax(attn, s, mask=mask, num_heads=self.num_heads)
         x, s = self.matmul_2(attn, s, v, s1)
         x = x.transpose(1, 2).reshape(B_, N, C)
         x, s = self.qact3(x, s)
@@ -221,6 +235,7 @@ class SwinTransformer(nn.Module):
         self.qact3 = QuantAct()
         self.head = QuantLinear(self.num_features, num_classes) if num_classes > 0 else nn.Identity()
         self.act_out = QuantAct()
+        self.fake_quant = False      # True: forward on the reference's fake-quant fp32 tensors, statement by statement
         # reference layout quirk: until the first PatchMerging (torch.cat) the fp32 activations keep the
         # token-contiguous layout of PatchEmbed's flatten(2).transpose(1,2), which changes torch's
         # summation order inside IntLayerNorm
@@ -243,7 +258,28 @@ class SwinTransformer(nn.Module):
                 mods[k].set_scale(v)
         return self
 
+    def _forward_features_fake(self, x):
+        """the reference's forward_features (swin_quant.py:540-556) statement by statement, on fake-quant fp32 tensors"""
+        if x.dtype == torch.int8:
+            s = self.qact_input.act_scaling_factor
+            x = to_fake(x, s)
+        else:
+            q, s = self.qact_input(x)
+            x = q if q.is_floating_point() else to_fake(q, s)
+        x, s = self.patch_embed(x, s)
+        x, s = self.qact1(x, s)
+        for layer in self.layers:
+            x, s = layer(x, s)
+        x, s = self.norm(x, s)
+        x, s = self.qact2(x, s)
+        x = torch.nn.functional.adaptive_avg_pool1d(x.transpose(1, 2), 1)      # B C 1, fp32 mean of fl(Q*s)
+        x = torch.flatten(x, 1)
+        x, s = self.qact3(x, s)
+        return x, s
+
     def forward_features(self, x):
+        if getattr(self, "fake_quant", False):
+            return self._forward_features_fake(x)
         if x.dtype == torch.int8:
             s = self.qact_input.act_scaling_factor
         else:

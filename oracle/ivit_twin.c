@@ -8,6 +8,7 @@
  * compositions of the restated operators of ivit_oracle.c (each of which cites the reference lines it follows), in the
  * order the reference's modules chain them; the reference citation of an entry point is the one in include/ivit.h.
  */
+#include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -393,4 +394,184 @@ int ivit_cpu_mlp_fused(ivit_handle h, const int8_t *x, const int8_t *w1, const i
     free(h8);
     free(g8);
     return rc;
+}
+
+/* ==== Swin-specific entry points and the planned fused Mlp (round 3: the rest of the operator-level header) ==== */
+void ivit_ref_shiftmax_masked(const int8_t *x, int64_t rows, int64_t n, int64_t ld_in, float s, int out_bits,
+                              const float *mask, int64_t nW, int64_t H, uint16_t *out, int64_t ld_out);
+void ivit_ref_layernorm_ord(const int16_t *x, int64_t rows, int64_t C, float s, const float *bias_int, const float *sc,
+                            float *z, int order, int64_t L);
+void ivit_ref_bmm_nt_i8(const int8_t *A, const int8_t *B, int32_t *C, int64_t nb, int64_t M, int64_t N, int64_t K);
+
+static inline int32_t tw_rq(double z, ivit_dyadic d) { return (int32_t)rint((z * d.m) * d.r); }
+static inline int32_t tw_clamp(int32_t v, int bits) {
+    const int32_t hi = (1 << (bits - 1)) - 1, lo = -hi - 1;
+    return v < lo ? lo : (v > hi ? hi : v);
+}
+
+int ivit_cpu_shiftmax_masked(ivit_handle h, const int8_t *x, int64_t rows, int n, int ld_in, float scale, int out_bits,
+                             const float *mask, int nW, int H, uint16_t *out, int ld_out) {
+    (void)h;
+    TW_REQ(x && out && rows > 0 && n > 0 && ld_in >= n && ld_out >= n && scale > 0.f && (out_bits == 8 || out_bits == 16));
+    TW_REQ(mask == NULL || (nW > 0 && H > 0));
+    ivit_ref_shiftmax_masked(x, rows, n, ld_in, scale, out_bits, mask, nW > 0 ? nW : 1, H > 0 ? H : 1, out, ld_out);
+    return TW_OK;
+}
+
+/* QuantAct with an identity that repeats every id_period elements (swin_quant.py:149) */
+int ivit_cpu_requant_i32_bcast(ivit_handle h, const int32_t *z, ivit_dyadic dy, const int32_t *z_id, int64_t id_period,
+                               ivit_dyadic dy_id, int bits, void *out, int64_t total) {
+    (void)h;
+    TW_REQ(z && z_id && out && id_period > 0 && total > 0 && (bits == 8 || bits == 16));
+    int32_t *t = (int32_t *)xmalloc((size_t)total * 4);
+    for (int64_t i = 0; i < total; ++i) t[i] = tw_clamp(tw_rq((double)z[i], dy) + tw_rq((double)z_id[i % id_period], dy_id), bits);
+    store_bits(t, bits, out, total);
+    free(t);
+    return TW_OK;
+}
+
+/* AdaptiveAvgPool1d(1) + QuantAct(8): L odd, so rne(sum(Q) / L) is the reference's round(fl(mean / s)) (ivit_oracle.c
+ * ivit_ref_avgpool_z restates the fp32 sequence; tests/test_oracle_golden.py pins the two against each other) */
+int ivit_cpu_avgpool_requant(ivit_handle h, const int8_t *x, int B, int L, int C, ivit_dyadic dy, int8_t *out8) {
+    (void)h;
+    TW_REQ(x && out8 && B > 0 && L > 0 && C > 0);
+    for (int64_t b = 0; b < B; ++b)
+        for (int64_t c = 0; c < C; ++c) {
+            long long sum = 0;
+            for (int64_t l = 0; l < L; ++l) sum += x[(b * L + l) * C + c];
+            const double z = rint((double)sum / (double)L);
+            out8[b * C + c] = (int8_t)tw_clamp(tw_rq(z, dy), 8);
+        }
+    return TW_OK;
+}
+
+int ivit_cpu_layernorm_tokenorder(ivit_handle h, const int16_t *x, int64_t rows, int C, float scale, const float *bias_int,
+                                  const float *sc, int tokens_per_image, float *z) {
+    (void)h;
+    TW_REQ(x && bias_int && sc && z && rows > 0 && C > 0 && scale > 0.f && tokens_per_image > 0);
+    ivit_ref_layernorm_ord(x, rows, C, scale, bias_int, sc, z, 1, tokens_per_image);
+    return TW_OK;
+}
+int ivit_cpu_layernorm_tokenorder_requant(ivit_handle h, const int16_t *x, int64_t rows, int C, float scale,
+                                          const float *bias_int, const float *sc, const ivit_dyadic *dy,
+                                          int tokens_per_image, int8_t *out8) {
+    TW_REQ(x && bias_int && sc && dy && out8 && rows > 0 && C > 0 && scale > 0.f && tokens_per_image > 0);
+    float *z = (float *)xmalloc((size_t)rows * C * 4);
+    ivit_ref_layernorm_ord(x, rows, C, scale, bias_int, sc, z, 1, tokens_per_image);
+    const int rc = ivit_cpu_requant_f32(h, z, dy, C, NULL, NULL, 8, out8, rows, C);
+    free(z);
+    return rc;
+}
+/* PatchEmbed's tail: int8 conv output -> norm (token-order sums) -> qact (16 bit, per channel) -> qact1 (16 bit, per tensor) */
+int ivit_cpu_patch_norm_tokenorder(ivit_handle h, const int8_t *x8, int64_t rows, int C, float scale, const float *bias_int,
+                                   const float *sc, const ivit_dyadic *dy_ch, ivit_dyadic dy2, int tokens_per_image,
+                                   int16_t *out16) {
+    TW_REQ(x8 && bias_int && sc && dy_ch && out16 && rows > 0 && C > 0 && scale > 0.f && tokens_per_image > 0);
+    int16_t *x16 = (int16_t *)xmalloc((size_t)rows * C * 2);
+    float *z = (float *)xmalloc((size_t)rows * C * 4);
+    int16_t *t16 = (int16_t *)xmalloc((size_t)rows * C * 2);
+    for (int64_t i = 0; i < rows * C; ++i) x16[i] = x8[i];
+    ivit_ref_layernorm_ord(x16, rows, C, scale, bias_int, sc, z, 1, tokens_per_image);
+    int rc = ivit_cpu_requant_f32(h, z, dy_ch, C, NULL, NULL, 16, t16, rows, C);
+    if (rc == TW_OK) rc = ivit_cpu_requant_i16(h, t16, &dy2, 1, NULL, NULL, 16, out16, rows, C);
+    free(x16);
+    free(z);
+    free(t16);
+    return rc;
+}
+
+/* PatchMerging's gather (swin_quant.py:336-342): cat([x[0::2,0::2], x[1::2,0::2], x[0::2,1::2], x[1::2,1::2]], -1) */
+int ivit_cpu_patch_merge_gather(ivit_handle h, const void *x, int in_bits, int B, int R, int C, int16_t *out) {
+    (void)h;
+    TW_REQ(x && out && B > 0 && R > 0 && (R % 2) == 0 && C > 0 && (in_bits == 8 || in_bits == 16));
+    const int R2 = R / 2;
+    for (int64_t b = 0; b < B; ++b)
+        for (int y = 0; y < R2; ++y)
+            for (int xx = 0; xx < R2; ++xx)
+                for (int blk = 0; blk < 4; ++blk) {
+                    const int sy = 2 * y + (blk & 1), sx = 2 * xx + (blk >> 1);
+                    const int64_t src = ((b * R + sy) * R + sx) * C, dst = (((b * R2 + y) * R2 + xx) * 4 + blk) * (int64_t)C;
+                    for (int c = 0; c < C; ++c)
+                        out[dst + c] = in_bits == 8 ? (int16_t)((const int8_t *)x)[src + c] : ((const int16_t *)x)[src + c];
+                }
+    return TW_OK;
+}
+int ivit_cpu_widen_i8_i16(ivit_handle h, const int8_t *x, int16_t *out, int64_t n) {
+    (void)h;
+    TW_REQ(x && out && n > 0);
+    for (int64_t i = 0; i < n; ++i) out[i] = x[i];
+    return TW_OK;
+}
+
+/* WindowAttention.forward between the qkv QuantAct and proj (swin_quant.py:121-162) with roll / window partition /
+ * reverse as index arithmetic (:18-50, 268-287), one (image, window, head) at a time in the reference's operator order */
+int ivit_cpu_window_attention_fused(ivit_handle h, const int8_t *qkv, ivit_dyadic dy_qk, ivit_dyadic dy_a, const int16_t *relb,
+                                    float s_softmax, ivit_dyadic dy_pv, int8_t *ctx, int B, int R, int window, int shift,
+                                    int heads, int dh) {
+    (void)h;
+    TW_REQ(qkv && relb && ctx && B > 0 && R > 0 && heads > 0 && window == 7 && dh == 32 && (R % 7) == 0 && shift >= 0 && shift < 7);
+    const int nw = R / 7, C = heads * 32, N = 49;
+    int8_t q[49 * 32], k[49 * 32], v[49 * 32], a8[49 * 49];
+    int32_t S[49 * 49], O[49 * 32];
+    uint16_t P[49 * 49];
+    float mask[49 * 49];
+    int64_t tok[49];
+    int reg[49];
+    for (int b = 0; b < B; ++b)
+        for (int wi = 0; wi < nw; ++wi)
+            for (int wj = 0; wj < nw; ++wj) {
+                for (int n = 0; n < N; ++n) {
+                    const int wy = n / 7, wx = n % 7, ys = wi * 7 + wy, xs = wj * 7 + wx;     /* coordinates in the ROLLED image */
+                    tok[n] = ((int64_t)b * R + (ys + shift) % R) * R + (xs + shift) % R;      /* torch.roll(x, -shift): rolled[y] = x[y + shift] */
+                    const int ry = ys < R - 7 ? 0 : (ys < R - shift ? 1 : 2), rx = xs < R - 7 ? 0 : (xs < R - shift ? 1 : 2);
+                    reg[n] = ry * 3 + rx;                                                      /* img_mask region (:276-287) */
+                }
+                for (int i = 0; i < N; ++i)
+                    for (int j = 0; j < N; ++j) mask[i * N + j] = (shift > 0 && reg[i] != reg[j]) ? -100.0f : 0.0f;
+                for (int hd = 0; hd < heads; ++hd) {
+                    for (int n = 0; n < N; ++n) {
+                        const int8_t *row = qkv + tok[n] * (3 * C) + hd * 32;
+                        memcpy(q + n * 32, row, 32);
+                        memcpy(k + n * 32, row + C, 32);
+                        memcpy(v + n * 32, row + 2 * C, 32);
+                    }
+                    ivit_ref_bmm_nt_i8(q, k, S, 1, N, N, 32);
+                    for (int i = 0; i < N * N; ++i) {
+                        const int32_t v1 = tw_clamp(tw_rq((double)S[i], dy_qk), 8);                          /* qact_attn1 */
+                        a8[i] = (int8_t)tw_clamp(tw_rq((double)v1, dy_a) + relb[(int64_t)hd * N * N + i], 8);  /* qact2 + bias */
+                    }
+                    ivit_ref_shiftmax_masked(a8, N, N, N, s_softmax, 8, shift > 0 ? mask : NULL, 1, 1, P, N);
+                    for (int i = 0; i < N; ++i)
+                        for (int d = 0; d < 32; ++d) {
+                            int32_t acc = 0;
+                            for (int j = 0; j < N; ++j) acc += (int32_t)P[i * N + j] * (int32_t)v[j * 32 + d];
+                            O[i * 32 + d] = acc;
+                        }
+                    for (int i = 0; i < N; ++i)
+                        for (int d = 0; d < 32; ++d)
+                            ctx[tok[i] * C + hd * 32 + d] = (int8_t)tw_clamp(tw_rq((double)O[i * 32 + d], dy_pv), 8);   /* qact3 */
+                }
+            }
+    return TW_OK;
+}
+
+/* planned fused Mlp: the twin keeps the two linear plans; the planned call is the unplanned chain */
+struct ivit_cpu_mlp_plan_s { const struct ivit_cpu_plan_s *fc1, *fc2; };
+int ivit_cpu_mlp_plan_create(ivit_handle h, ivit_linear_plan fc1, ivit_linear_plan fc2, ivit_mlp_plan *out) {
+    (void)h;
+    const struct ivit_cpu_plan_s *p1 = (const struct ivit_cpu_plan_s *)fc1, *p2 = (const struct ivit_cpu_plan_s *)fc2;
+    TW_REQ(p1 && p2 && out);
+    if (p1->K != 384 || p1->N != 1536 || p2->K != 1536 || p2->N != 384) return 3;      /* IVIT_ERR_UNSUPPORTED, like the HIP side */
+    struct ivit_cpu_mlp_plan_s *p = (struct ivit_cpu_mlp_plan_s *)xmalloc(sizeof(*p));
+    p->fc1 = p1; p->fc2 = p2;
+    *out = (ivit_mlp_plan)p;
+    return TW_OK;
+}
+int ivit_cpu_mlp_plan_destroy(ivit_mlp_plan p) { free(p); return TW_OK; }
+int ivit_cpu_mlp_fused_planned(ivit_handle h, ivit_mlp_plan p, const int8_t *x, const int8_t *gelu_table, ivit_dyadic dy_main,
+                               ivit_dyadic dy_res, const int16_t *residual, int16_t *out, int64_t M) {
+    const struct ivit_cpu_mlp_plan_s *pl = (const struct ivit_cpu_mlp_plan_s *)p;
+    TW_REQ(pl && x && gelu_table && residual && out && M > 0);
+    return ivit_cpu_mlp_fused(h, x, pl->fc1->w, pl->fc1->bias, pl->fc1->dy, gelu_table, pl->fc2->w, pl->fc2->bias, pl->fc2->dy,
+                              dy_main, dy_res, residual, out, M, pl->fc1->K, pl->fc1->N);
 }

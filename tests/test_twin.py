@@ -35,7 +35,7 @@ def twin():
 
 # the two plan calls without a handle argument are declared outside _lib.SIGNATURES (which prepends nothing, but whose
 # Handle.call wrapper does): same argtypes as _lib.load() sets
-_EXTRA = {"linear_plan_destroy": [_P], "linear_plan_query": [_P, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]}
+_EXTRA = {"linear_plan_destroy": [_P], "mlp_plan_destroy": [_P], "linear_plan_query": [_P, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]}
 
 
 def _sig(name):
@@ -175,6 +175,38 @@ def _cases(rng):
     Te, De = 17, 64
     cs.append(("embed_finish", [I(rng.integers(-20000, 20000, (2, Te - 1, De)).astype(np.int16)), I(rng.integers(-10 ** 6, 10 ** 6, De).astype(np.int32)),
                                 I(rng.integers(-20000, 20000, (Te, De)).astype(np.int16)), dyv(dm), dyv(dr), O(np.zeros((2, Te, De), np.int16)), 2, Te, De]))
+    # ---- round 3: Swin-specific operators
+    a49 = rng.integers(-128, 128, (8 * 3 * 49, 49), dtype=np.int8)                     # [B_ = 8, H = 3, 49] rows
+    mk = np.where(rng.random((4, 49, 49)) < 0.3, np.float32(-100.0), np.float32(0.0)).astype(np.float32)
+    cs.append(("shiftmax_masked", [I(a49), 8 * 3 * 49, 49, 49, 0.05, 8, I(mk), 4, 3, O(np.zeros((8 * 3 * 49, 49), np.uint16)), 49]))
+    cs.append(("shiftmax_masked", [I(a49), 8 * 3 * 49, 49, 49, 0.05, 8, None, 0, 0, O(np.zeros((8 * 3 * 49, 49), np.uint16)), 49]))
+    zb = rng.integers(-128, 128, 6 * 3 * 2401).astype(np.int32)
+    zi = rng.integers(-128, 128, 3 * 2401).astype(np.int32)
+    da, db = iv.freeze.dyadic(np.float32(0.04), np.float32(0.05)), iv.freeze.dyadic(np.float32(0.01), np.float32(0.05))
+    cs.append(("requant_i32_bcast", [I(zb), dyv(da), I(zi), 3 * 2401, dyv(db), 8, O(np.zeros(6 * 3 * 2401, np.int8)), 6 * 3 * 2401]))
+    cs.append(("avgpool_requant", [I(rng.integers(-128, 128, (3, 49, 96), dtype=np.int8)), 3, 49, 96, dyv(iv.freeze.dyadic(np.float32(0.03), np.float32(0.02))),
+                                   O(np.zeros((3, 96), np.int8))]))
+    Ct, Lt = 96, 64                                                                     # token-order sums: 2 images of 64 tokens
+    xt = rng.integers(-9000, 9000, (2 * Lt, Ct)).astype(np.int16)
+    wt, bt = rng.uniform(0.4, 1.6, Ct).astype(np.float32), rng.normal(0, 0.3, Ct).astype(np.float32)
+    bit, sct = iv.freeze.layernorm_constants(wt, bt)
+    dt8, dt16 = iv.freeze.dyadic(sct, np.float32(0.03)), iv.freeze.dyadic(sct, np.float32(2e-4))
+    cs.append(("layernorm_tokenorder", [I(xt), 2 * Lt, Ct, 2.5e-4, I(bit), I(sct), Lt, O(np.zeros((2 * Lt, Ct), np.float32))]))
+    cs.append(("layernorm_tokenorder_requant", [I(xt), 2 * Lt, Ct, 2.5e-4, I(bit), I(sct), I(dt8), Lt, O(np.zeros((2 * Lt, Ct), np.int8))]))
+    cs.append(("patch_norm_tokenorder", [I(rng.integers(-128, 128, (2 * Lt, Ct), dtype=np.int8)), 2 * Lt, Ct, 0.02, I(bit), I(sct), I(dt16),
+                                         dyv(iv.freeze.dyadic(np.float32(2e-4), np.float32(2.5e-4))), Lt, O(np.zeros((2 * Lt, Ct), np.int16))]))
+    pm = rng.integers(-20000, 20000, (2, 14, 14, 96)).astype(np.int16)
+    cs.append(("patch_merge_gather", [I(pm), 16, 2, 14, 96, O(np.zeros((2, 49, 384), np.int16))]))
+    cs.append(("patch_merge_gather", [I(rng.integers(-128, 128, (2, 14, 14, 96), dtype=np.int8)), 8, 2, 14, 96, O(np.zeros((2, 49, 384), np.int16))]))
+    cs.append(("widen_i8_i16", [I(rng.integers(-128, 128, 5000, dtype=np.int8)), O(np.zeros(5000, np.int16)), 5000]))
+    # windowed attention: 2 images of 14 x 14 tokens (2 x 2 windows), 3 heads, with and without the cyclic shift
+    Bw, Rw, Hw = 2, 14, 3
+    qkvw = rng.integers(-128, 128, (Bw, Rw, Rw, 3 * Hw * 32), dtype=np.int8)
+    relb = rng.integers(-60, 60, (Hw, 49, 49)).astype(np.int16)
+    dwq, dwa, dwp = (iv.freeze.dyadic(np.float32(a), np.float32(b)) for a, b in ((3e-4, 0.05), (0.05, 0.06), (4e-4, 0.03)))
+    for sh in (0, 3):
+        cs.append(("window_attention_fused", [I(qkvw), dyv(dwq), dyv(dwa), I(relb), 0.06, dyv(dwp), O(np.zeros((Bw, Rw * Rw, Hw * 32), np.int8)),
+                                              Bw, Rw, 7, sh, Hw, 32]))
     return cs
 
 
@@ -250,10 +282,45 @@ def test_every_twinned_entry_point_agrees_with_the_hip_library(twin):
     assert np.array_equal(og.cpu().numpy(), oc)
     H.lib.ivit_linear_plan_destroy.argtypes = [_P]
     assert H.lib.ivit_linear_plan_destroy(pg) == 0 and twin.ivit_cpu_linear_plan_destroy(pc) == 0
+    # planned fused Mlp (D = 384): linear plans -> Mlp plan -> one call, on both sides
+    Mm, Cm, Hm = 333, 384, 1536
+    xm = rng.integers(-128, 128, (Mm, Cm), dtype=np.int8)
+    w1 = np.rint(rng.normal(0, 40, (Hm, Cm)).clip(-127, 127)).astype(np.int8); b1 = rng.integers(-2000, 2000, Hm).astype(np.int32)
+    w2 = np.rint(rng.normal(0, 40, (Cm, Hm)).clip(-127, 127)).astype(np.int8); b2 = rng.integers(-2000, 2000, Cm).astype(np.int32)
+    d1 = iv.freeze.dyadic((10 ** rng.uniform(-5.6, -5.3, Hm)).astype(np.float32), np.float32(0.04))
+    d2 = iv.freeze.dyadic((10 ** rng.uniform(-5.9, -5.6, Cm)).astype(np.float32), np.float32(2e-4))
+    dmm, drr = iv.freeze.dyadic(np.float32(2e-4), np.float32(2.5e-4)), iv.freeze.dyadic(np.float32(3e-4), np.float32(2.5e-4))
+    resm = rng.integers(-20000, 20000, (Mm, Cm)).astype(np.int16)
+    tabm = np.zeros(65536, np.int8)
+    dgm = iv.freeze.dyadic(np.float32(0.04 * 2.0 ** -7), np.float32(0.03))
+    assert twin.ivit_cpu_shiftgelu_build_table(None, 0.04, dyv(dgm), hp(tabm)) == 0
+    tabd = torch.empty(65536, dtype=torch.int8, device="cuda")
+    H.call("ivit_shiftgelu_build_table", 0.04, dyv(dgm), _P(tabd.data_ptr()))
+    dev = {k: torch.from_numpy(v).cuda() for k, v in dict(x=xm, w1=w1, b1=b1, w2=w2, b2=b2, d1=d1, d2=d2, res=resm).items()}
+    g1, g2, gm, c1, c2, cm = (_P() for _ in range(6))
+    f = H.lib.ivit_linear_plan_create
+    assert f(H.h, _P(dev["w1"].data_ptr()), _P(dev["b1"].data_ptr()), _P(dev["d1"].data_ptr()), Hm, Cm, ctypes.byref(g1)) == 0
+    assert f(H.h, _P(dev["w2"].data_ptr()), _P(dev["b2"].data_ptr()), _P(dev["d2"].data_ptr()), Cm, Hm, ctypes.byref(g2)) == 0
+    assert twin.ivit_cpu_linear_plan_create(None, hp(w1), hp(b1), hp(d1), Hm, Cm, ctypes.byref(c1)) == 0
+    assert twin.ivit_cpu_linear_plan_create(None, hp(w2), hp(b2), hp(d2), Cm, Hm, ctypes.byref(c2)) == 0
+    H.call("ivit_mlp_plan_create", g1, g2, ctypes.byref(gm))
+    assert twin.ivit_cpu_mlp_plan_create(None, c1, c2, ctypes.byref(cm)) == 0
+    assert twin.ivit_cpu_mlp_plan_create(None, c2, c1, ctypes.byref(_P())) == 3          # other shapes: unsupported on both sides
+    og, oc = torch.zeros(Mm, Cm, dtype=torch.int16, device="cuda"), np.zeros((Mm, Cm), np.int16)
+    H.call("ivit_mlp_fused_planned", gm, _P(dev["x"].data_ptr()), _P(tabd.data_ptr()), dyv(dmm), dyv(drr), _P(dev["res"].data_ptr()),
+           _P(og.data_ptr()), Mm)
+    assert twin.ivit_cpu_mlp_fused_planned(None, cm, hp(xm), hp(tabm), dyv(dmm), dyv(drr), hp(resm), hp(oc), Mm) == 0
+    assert np.array_equal(og.cpu().numpy(), oc)
+    assert H.lib.ivit_mlp_plan_destroy(gm) == 0 and twin.ivit_cpu_mlp_plan_destroy(cm) == 0
+    for pl in (g1, g2):
+        assert H.lib.ivit_linear_plan_destroy(pl) == 0
+    for pl in (c1, c2):
+        assert twin.ivit_cpu_linear_plan_destroy(pl) == 0
     # every twinned single-call entry point was exercised above (plans and the LUT forms have their own protocol)
     rest = set(gen_twin_header.TWIN) - seen - {"linear_plan_create", "linear_plan_destroy", "linear_plan_query",
                                                 "linear_i8_requant_planned", "linear_i8_requant_residual_planned",
-                                                "linear_i8_qkv_planned", "attention_fused_lut", "shiftgelu_requant_lut", "mlp_fused"}
+                                                "linear_i8_qkv_planned", "attention_fused_lut", "shiftgelu_requant_lut", "mlp_fused",
+                                                "mlp_plan_create", "mlp_plan_destroy", "mlp_fused_planned"}
     assert not rest, rest
 
 
