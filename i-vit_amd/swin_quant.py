@@ -76,8 +76,21 @@ class WindowAttention(nn.Module):
         fake = _is_fake(attn)
         if fake:
             attn = attn * self.scale
+        s_mm = s
         s = torch.from_numpy((_f32(s) * np.float32(self.scale)).astype(np.float32))
-        attn, s = self.qact_attn1(attn, s)
+        if self.qact_attn1.running_stat and not fake:
+            # calibration: the reference tracks the range of fl(fl(acc * s) * scale) — TWO roundings (swin_quant.py:132-133:
+            # matmul_1 returns acc * s, then `attn * self.scale`), not fl(acc * fl(s * scale)); with head dim 32 the factor
+            # 32^-0.5 is not a power of two and the two differ by an ulp on the tracked maximum
+            Xr = (attn.float() * torch.as_tensor(_f32(s_mm), device=attn.device)) * self.scale
+            self.qact_attn1._collect_range(Xr, None, None, None)
+            self.qact_attn1.running_stat = False
+            try:
+                attn, s = self.qact_attn1(attn, s)
+            finally:
+                self.qact_attn1.running_stat = True
+        else:
+            attn, s = self.qact_attn1(attn, s)
         tab_q, s_tab = self.qact_table(self.relative_position_bias_table.detach().to(x.device))
         if fake and not _is_fake(tab_q):
             tab_q = to_fake(tab_q, s_tab)

@@ -114,7 +114,7 @@ def test_deit_logits_and_site_checksums(fname):
     assert all(b.endswith("attn.matmul_2") for b in bad), bad
 
 
-@pytest.mark.parametrize("fname,full", [("micro_swin_b2.npz", True), ("swin_tiny_b1.npz", False)])
+@pytest.mark.parametrize("fname,full", [("micro_swin_b2.npz", True), ("swin_tiny_b1.npz", False), ("swin_base_b1.npz", False)])
 def test_swin_oracle_vs_reference(fname, full):
     """OracleSwin (incl. masked 8-bit Shiftmax, rel-pos bias requant, token-order LayerNorm in
     stage 0, patch merging, avg-pool) against every site the reference produced."""

@@ -288,6 +288,10 @@ def main():
         model_fixture(models, "vit_large", 1, 1, 0, False, "vit_large_b1.npz")
         swin_fixture(models, "swin_small", 1, 1, 0, False, "swin_small_b1.npz")
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "--swin-base":
+        # swin_base_patch4_window7_224 (swin_quant.py:609-627): embed 128, heads 4/8/16/32 — channel counts no other fixture has
+        swin_fixture(models, "swin_base", 1, 1, 0, False, "swin_base_b1.npz")
+        return
     op_fixtures(models)
     model_fixture(models, "micro_vit", 2, 4, 0, True, "micro_vit_b2.npz")
     model_fixture(models, "micro_vit2h", 3, 4, 0, True, "micro_vit2h_b3.npz")
