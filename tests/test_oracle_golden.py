@@ -181,3 +181,18 @@ def test_resize_center_crop_oracle_vs_torch_fixture():
         total += d.size
         diff += int((d > 0).sum())
     assert diff <= 1e-3 * total, (diff, total)
+
+
+@pytest.mark.parametrize("fname", ["micro_vit_b2.npz", "micro_vit2h_b3.npz", "deit_tiny_b1.npz"])
+def test_torch_ref_matches_golden_logits(fname):
+    """oracle/torch_ref.py — the PyTorch-CPU counterpart of the reference's fake-quant path that bench.py times as
+    `cpu_baseline` — reproduces the reference's int32 logits: logits / per-class scale == golden."""
+    import torch
+    from oracle.torch_ref import TorchRefViT
+    g = load_golden(fname)
+    cfg = iv.CONFIGS[str(g["cfg_name"])]
+    m = TorchRefViT(cfg, iv.make_vit_weights(cfg, int(g["seed"])), golden_scales(g))
+    logits, sc = m.forward(iv.make_images_int8(cfg, int(g["batch"]), int(g["images_seed"])))
+    assert logits.dtype == torch.float32
+    assert np.array_equal(torch.round(logits / sc).numpy().astype(np.int64), g["logits_int"])
+    assert np.array_equal(sc.numpy(), g["logits_scale"])
