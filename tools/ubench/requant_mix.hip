@@ -14,6 +14,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 tools/ubench/requant_mix.hip -o tools/ubench/requant_mix
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
@@ -262,6 +263,11 @@ int main() {
 #define R3(MIX, name)                                                                          \
     run<MIX, 1, 1, 2>(buf, clk, name); run<MIX, 2, 1, 2>(buf, clk, name); run<MIX, 1, 0, 2>(buf, clk, name); \
     run<MIX, 2, 1, 1>(buf, clk, name);
+    if (getenv("ACC_SWEEP")) {   // dependent chains: how many independent accumulators a wave needs, 1..3 waves per SIMD
+        peak<32, 1, 1>(buf, clk, 1); peak<32, 2, 1>(buf, clk, 1); peak<32, 1, 3>(buf, clk, 1); peak<32, 2, 3>(buf, clk, 1);
+        peak<32, 2, 2>(buf, clk, 1); peak<32, 4, 3>(buf, clk, 1); peak<16, 2, 3>(buf, clk, 1); peak<16, 4, 3>(buf, clk, 1);
+        return 0;
+    }
     for (int seed = 0; seed < 2; ++seed) {
         peak<32, 4, 1>(buf, clk, seed); peak<32, 4, 2>(buf, clk, seed); peak<32, 4, 4>(buf, clk, seed);
         peak<16, 8, 1>(buf, clk, seed); peak<16, 16, 1>(buf, clk, seed); peak<16, 8, 2>(buf, clk, seed);
