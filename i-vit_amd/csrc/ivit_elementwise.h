@@ -543,38 +543,67 @@ __global__ __launch_bounds__(256) void im2col_patch_kernel(const int8_t *__restr
     }
 }
 
+// P = 16: a patch row (c, py) is exactly one 16-byte chunk on both sides, so the strip moves as 16-byte chunks with no
+// division by a run-time value (the generic kernel above spends ~26 VALU instructions per BYTE on them: 1.6e7
+// wave-instructions per launch at batch 256).  Threads are a 16 x 16 grid over (x chunk, strip row) for the load — the
+// row's channel advances by one every 16 rows — and walk (patch, row) pairs with a compile-time divisor for the store.
+template <int CIN>
+__global__ __launch_bounds__(256) void im2col_patch16_kernel(const int8_t *__restrict__ img, int H, int W, int8_t *__restrict__ rows) {
+    extern __shared__ __attribute__((aligned(16))) char dsmem[];
+    constexpr int P = 16, R = CIN * P, K = CIN * P * P;
+    const int gh = H / P, gw = W / P, wc = W / 16;
+    const int b = blockIdx.y, gy = blockIdx.x;
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int8_t *src = img + ((long long)b * CIN * H + gy * P + ty) * W;      // channel 0, strip row ty
+#pragma unroll
+    for (int c = 0; c < CIN; ++c)
+        for (int xc = tx; xc < wc; xc += 16)
+            *reinterpret_cast<v4i *>(dsmem + (c * P + ty) * W + xc * 16) =
+                *reinterpret_cast<const v4i *>(src + (long long)c * H * W + xc * 16);
+    __syncthreads();
+    int8_t *dst = rows + ((long long)b * gh + gy) * gw * K;
+    for (int q = tid; q < gw * R; q += 256) {
+        const int gx = q / R, r = q - gx * R;                                  // R is a compile-time constant
+        *reinterpret_cast<v4i *>(dst + q * 16) = *reinterpret_cast<const v4i *>(dsmem + r * W + gx * 16);
+    }
+}
+
 // class token + position embedding (vit_quant.py:259-265)
 __global__ __launch_bounds__(256) void embed_finish_kernel(const int16_t *__restrict__ patch16,
                                                            const int32_t *__restrict__ z_cls,
                                                            const int16_t *__restrict__ pos, ivit_dyadic dx,
-                                                           ivit_dyadic dp, int16_t *__restrict__ x16, int B, int T,
-                                                           int D) {
-    // one thread per 8 channels (16-byte loads/stores); all index arithmetic in 32 bits, once per thread
-    const int D8 = D >> 3;
-    const long long total = (long long)B * T * D8;
+                                                           ivit_dyadic dp, int16_t *__restrict__ x16, int T,
+                                                           int D, float inv_d8, int fast) {
+    // one thread per 8 channels (16-byte loads/stores), one image per blockIdx.y; (token, channel group) from the flat index
+    // by a float reciprocal (exact: T * D / 8 < 2^22), no integer division
+    const int D8 = D >> 3, b = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= T * D8) return;
+    const int t = (int)(((float)idx + 0.5f) * inv_d8), c8 = idx - t * D8;
     const double cx = dx.m * dx.r, cp = dp.m * dp.r;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int row = (int)(i / D8), c8 = (int)(i - (long long)row * D8);
-        const int b = row / T, t = row - b * T;
-        const v8s pv = *reinterpret_cast<const v8s *>(pos + (long long)t * D + c8 * 8);
-        int z[8];
-        if (t == 0) {
-            const v4i a0 = *reinterpret_cast<const v4i *>(z_cls + c8 * 8), a1 = *reinterpret_cast<const v4i *>(z_cls + c8 * 8 + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { z[e] = a0[e]; z[4 + e] = a1[e]; }
-        } else {
-            const v8s xv = *reinterpret_cast<const v8s *>(patch16 + ((long long)b * (T - 1) + (t - 1)) * D + c8 * 8);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) z[e] = xv[e];
-        }
-        v8s o;
+    const v8s pv = *reinterpret_cast<const v8s *>(pos + (long long)t * D + c8 * 8);
+    v8s o;
+    if (t == 0) {                      // class token: int32 accumulators, the general requant
+        const v4i a0 = *reinterpret_cast<const v4i *>(z_cls + c8 * 8), a1 = *reinterpret_cast<const v4i *>(z_cls + c8 * 8 + 4);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const double v = __builtin_rint((double)pv[e] * cp) + __builtin_rint((double)z[e] * cx);
+            const double v = __builtin_rint((double)pv[e] * cp) + __builtin_rint((double)(e < 4 ? a0[e] : a1[e - 4]) * cx);
             o[e] = (short)clamp_b<16>(v);
         }
-        *reinterpret_cast<v8s *>(x16 + i * 8) = o;
+    } else {
+        const v8s xv = *reinterpret_cast<const v8s *>(patch16 + ((long long)b * (T - 1) + (t - 1)) * D + c8 * 8);
+        if (fast) {                    // 16-bit operands, |c| < 2^9: one fma + low dword each (rq_fast), integer sum and clamp
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (short)min(max(rq_fast((int)pv[e], cp) + rq_fast((int)xv[e], cx), -32768), 32767);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const double v = __builtin_rint((double)pv[e] * cp) + __builtin_rint((double)xv[e] * cx);
+                o[e] = (short)clamp_b<16>(v);
+            }
+        }
     }
+    *reinterpret_cast<v8s *>(x16 + ((long long)b * T + t) * D + c8 * 8) = o;
 }
 
 // ---------------------------------------------------------------------------

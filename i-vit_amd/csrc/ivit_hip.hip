@@ -990,7 +990,10 @@ int ivit_im2col_patch(ivit_handle h, const int8_t *img, int B, int Cin, int H, i
     REQUIRE(h, (H % P) == 0 && (W % P) == 0 && (P % 4) == 0 && (W % 4) == 0, "H,W multiples of P; P,W multiples of 4");
     const size_t lds = (size_t)Cin * P * W;
     REQUIRE(h, lds <= 64 * 1024, "patch strip too large for LDS staging");
-    im2col_patch_kernel<<<(unsigned)(B * (H / P)), 256, lds, h->stream>>>(img, B, Cin, H, W, P, rows);
+    if (P == 16 && Cin == 3 && (W % 16) == 0 && B <= 65535)
+        im2col_patch16_kernel<3><<<dim3((unsigned)(H / P), (unsigned)B), 256, lds, h->stream>>>(img, H, W, rows);
+    else
+        im2col_patch_kernel<<<(unsigned)(B * (H / P)), 256, lds, h->stream>>>(img, B, Cin, H, W, P, rows);
     LAUNCH_CHECK(h);
     return IVIT_OK;
 }
@@ -999,7 +1002,10 @@ int ivit_embed_finish(ivit_handle h, const int16_t *patch16, const int32_t *z_cl
                       ivit_dyadic dy_x, ivit_dyadic dy_pos, int16_t *x16, int B, int T, int D) {
     CHECK_H(h);
     REQUIRE(h, patch16 && z_cls && pos && x16 && B > 0 && T > 1 && D > 0 && (D % 8) == 0, "bad arguments (D must be a multiple of 8)");
-    embed_finish_kernel<<<grid_for(h, (long long)B * T * D / 8, 256), 256, 0, h->stream>>>(patch16, z_cls, pos, dy_x, dy_pos, x16, B, T, D);
+    REQUIRE(h, (long long)T * D / 8 < (1 << 22) && B <= 65535, "T * D / 8 < 2^22, B < 2^16");
+    const int fast = fabs(dy_x.m * dy_x.r) < RQ_FAST_CLIM && fabs(dy_pos.m * dy_pos.r) < RQ_FAST_CLIM;
+    embed_finish_kernel<<<dim3((unsigned)((T * (D / 8) + 255) / 256), (unsigned)B), 256, 0, h->stream>>>(
+        patch16, z_cls, pos, dy_x, dy_pos, x16, T, D, 1.0f / (float)(D / 8), fast);
     LAUNCH_CHECK(h);
     return IVIT_OK;
 }
