@@ -837,14 +837,17 @@ int ivit_layernorm_requant(ivit_handle h, const int16_t *x, int64_t rows, int C,
             return IVIT_OK;                                                                                     \
         } while (0)
         switch (C) {
-            // lanes per row = 4 S: <= 64 values per lane (measured on DeiT-S b256: S = 1 23.2 us, S = 2 20.1, S = 4 20.2 —
-            // shorter per-wave instruction chains and more waves per SIMD beat the cheaper quad-only reduction)
-            case 96: LNR_LAUNCH(96, 1);        // Swin-T/S stage 0 (token-order sums use their own kernel)
-            case 128: LNR_LAUNCH(128, 1);      // Swin-B stage 0
-            case 192: LNR_LAUNCH(192, 1);      // DeiT-T, Swin stage 1
+            // lanes per row = 4 S (measured on DeiT-S b256: S = 1 23.2 us, S = 2 20.1, S = 4 20.2 — shorter per-wave instruction
+            // chains and more waves per SIMD beat the cheaper quad-only reduction).  S = 1 is NOT dispatched: under
+            // co-residency with GEMM workgroups layernorm_reg_kernel<192, 1> produced sporadic one-LSB differences in a few
+            // adjacent rows (tools/op_stress.py; S = 2 on the same shape: none in 960 launches) — its ISA interleaves
+            // v_pk_add_f32 with v_mov_b32_dpp writes to the packed instruction's source registers
+            case 96: LNR_LAUNCH(96, 2);        // Swin-T/S stage 0 (token-order sums use their own kernel)
+            case 128: LNR_LAUNCH(128, 2);      // Swin-B stage 0
+            case 192: LNR_LAUNCH(192, 2);      // DeiT-T, Swin stage 1
             case 256: LNR_LAUNCH(256, 2);
             case 384: LNR_LAUNCH(384, 2);      // DeiT-S, Swin stage 2, PatchMerging
-            case 512: LNR_LAUNCH(512, 2);
+            case 512: LNR_LAUNCH(512, 4);
             case 768: LNR_LAUNCH(768, 4);      // DeiT-B / ViT-B, Swin stage 3
             case 1024: LNR_LAUNCH(1024, 4);    // ViT-L
             case 1536: LNR_LAUNCH(1536, 4);    // Swin PatchMerging before stage 3
@@ -920,9 +923,14 @@ int ivit_layernorm_tokenorder_requant(ivit_handle h, const int16_t *x, int64_t r
     REQUIRE(h, x && bias_int && sc && dy && out8 && rows > 0 && C > 0 && scale > 0.f && tokens_per_image > 0, "bad arguments");
     const size_t lds = ((size_t)LNT_ROWS * (C + 1) + 3 * (size_t)C + 2 * LNT_ROWS + 2) * sizeof(float) + (size_t)C * sizeof(double);
     REQUIRE(h, lds <= 160 * 1024, "C too large for LDS staging");
-    if (C == 96) {          // Swin-T/S stage 0
-        layernorm_tokenorder_kernel<1, 96><<<(unsigned)((rows + LNT_ROWS - 1) / LNT_ROWS), 256, lds, h->stream>>>(
-            x, rows, C, scale, bias_int, sc, dy, tokens_per_image, out8);
+    if (C == 96 || C == 128) {          // Swin-T/S and Swin-B stage 0
+        const size_t lds8 = ((size_t)LNT8_ROWS * (C + 1) + C + 2 * LNT8_ROWS) * sizeof(float);
+        const unsigned g8 = (unsigned)((rows + LNT8_ROWS - 1) / LNT8_ROWS);
+        const void *fn = C == 96 ? (const void *)layernorm_tokenorder8_kernel<1, 96, int16_t> : (const void *)layernorm_tokenorder8_kernel<1, 128, int16_t>;
+        int st = set_dyn_lds(h, fn, lds8);
+        if (st) return st;
+        if (C == 96) layernorm_tokenorder8_kernel<1, 96, int16_t><<<g8, 96 / 8 * 16, lds8, h->stream>>>(x, rows, scale, bias_int, sc, dy, tokens_per_image, out8, ivit_dyadic{0.0, 0.0});
+        else layernorm_tokenorder8_kernel<1, 128, int16_t><<<g8, 128 / 8 * 16, lds8, h->stream>>>(x, rows, scale, bias_int, sc, dy, tokens_per_image, out8, ivit_dyadic{0.0, 0.0});
     } else {
         int st = set_dyn_lds(h, (const void *)layernorm_tokenorder_kernel<1, 0>, lds);
         if (st) return st;
@@ -941,9 +949,14 @@ int ivit_patch_norm_tokenorder(ivit_handle h, const int8_t *x8, int64_t rows, in
     const size_t lds = ((size_t)LNT_ROWS * (C + 1) + 3 * (size_t)C + 2 * LNT_ROWS + 2) * sizeof(float) + (size_t)C * sizeof(double);
     REQUIRE(h, lds <= 160 * 1024, "C too large for LDS staging");
     const unsigned grid = (unsigned)((rows + LNT_ROWS - 1) / LNT_ROWS);
-    if (C == 96) {
-        layernorm_tokenorder_kernel<2, 96, int8_t><<<grid, 256, lds, h->stream>>>(x8, rows, C, scale, bias_int, sc, dy_ch,
-                                                                            tokens_per_image, out16, dy2);
+    if (C == 96 || C == 128) {
+        const size_t lds8 = ((size_t)LNT8_ROWS * (C + 1) + C + 2 * LNT8_ROWS) * sizeof(float);
+        const unsigned g8 = (unsigned)((rows + LNT8_ROWS - 1) / LNT8_ROWS);
+        const void *fn = C == 96 ? (const void *)layernorm_tokenorder8_kernel<2, 96, int8_t> : (const void *)layernorm_tokenorder8_kernel<2, 128, int8_t>;
+        int st = set_dyn_lds(h, fn, lds8);
+        if (st) return st;
+        if (C == 96) layernorm_tokenorder8_kernel<2, 96, int8_t><<<g8, 96 / 8 * 16, lds8, h->stream>>>(x8, rows, scale, bias_int, sc, dy_ch, tokens_per_image, out16, dy2);
+        else layernorm_tokenorder8_kernel<2, 128, int8_t><<<g8, 128 / 8 * 16, lds8, h->stream>>>(x8, rows, scale, bias_int, sc, dy_ch, tokens_per_image, out16, dy2);
     } else {
         int st = set_dyn_lds(h, (const void *)layernorm_tokenorder_kernel<2, 0, int8_t>, lds);
         if (st) return st;

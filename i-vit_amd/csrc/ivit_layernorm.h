@@ -49,10 +49,12 @@ __device__ __forceinline__ float ln_dpp(float v) {
 #ifndef LNR_ABLATE
 #define LNR_ABLATE 0
 #endif
-// register budget by lanes per row: 96 / 48 / 24 values per lane -> 4 / 5 / 8 waves per SIMD
-#define LNR_MIN_WAVES(S) ((S) == 1 ? 4 : ((S) == 2 ? 5 : 8))
+// register budget by values per lane (CC / 4S): <= 24 -> 8 waves per SIMD, <= 48 -> 5, <= 64 -> 4, more -> 3 (no scratch in any
+// instantiation the dispatcher uses)
+#define LNR_VPL(CC, S) ((CC) / (4 * (S)))
+#define LNR_MIN_WAVES(CC, S) (LNR_VPL(CC, S) <= 24 ? 8 : (LNR_VPL(CC, S) <= 48 ? 5 : (LNR_VPL(CC, S) <= 64 ? 4 : 3)))
 template <int CC, int S>
-__global__ __launch_bounds__(LNR_THREADS(S), LNR_MIN_WAVES(S)) void layernorm_reg_kernel(const int16_t *__restrict__ x, long long rows,
+__global__ __launch_bounds__(LNR_THREADS(S), LNR_MIN_WAVES(CC, S)) void layernorm_reg_kernel(const int16_t *__restrict__ x, long long rows,
                                                                      long long row_stride, float s,
                                                                      const float *__restrict__ bias_int,
                                                                      const float *__restrict__ sc,

@@ -200,6 +200,118 @@ __global__ __launch_bounds__(256) void layernorm_tokenorder_kernel(const XT *__r
     }
 }
 
+// The same operator for the stage-0 channel counts (C = 96, 128), 128 tokens per block, 8 channels per thread: 16-byte
+// loads and 8 / 16-byte stores (the kernel above moves one element per thread-iteration: 2-byte loads, 1-byte stores,
+// and runs its serial phase on 32 of 256 threads).  A thread keeps ONE channel group for the whole block — block size
+// (C / 8) x 16 — so its eight per-channel constants live in registers; the order-sensitive sums and the integer square
+// root run on 128 threads, one token each, on rows staged as fp32 with an odd pitch (conflict-free per-token walks).
+#define LNT8_ROWS 128
+template <int OUTM, int CC, typename XT>
+__global__ __launch_bounds__(CC / 8 * 16) void layernorm_tokenorder8_kernel(const XT *__restrict__ x, long long rows, float s,
+                                                                            const float *__restrict__ bias_int,
+                                                                            const float *__restrict__ sc,
+                                                                            const ivit_dyadic *__restrict__ dy, int L,
+                                                                            void *__restrict__ out, ivit_dyadic dy2) {
+    static_assert(OUTM == 1 || OUTM == 2, "int8 or twice-requantised int16 output");
+    constexpr int NC8 = CC / 8, NT = NC8 * 16, LD = CC + 1, NIT = LNT8_ROWS / 16;
+    extern __shared__ __attribute__((aligned(16))) char dsmem[];
+    float *tile = reinterpret_cast<float *>(dsmem);            // [LNT8_ROWS][CC + 1]
+    float *cY = tile + LNT8_ROWS * LD, *rMean = cY + CC, *rF = rMean + LNT8_ROWS;
+    const int tid = threadIdx.x, c8 = tid % NC8, rr = tid / NC8;
+    const long long row0 = (long long)blockIdx.x * LNT8_ROWS;
+    const float ys = rcp_rn(s);
+    for (int c = tid; c < CC; c += NT) cY[c] = rcp_rn(sc[c]);
+    float scv[8], bv[8];
+    double cv[8];
+    {
+        const v4f s0 = *reinterpret_cast<const v4f *>(sc + c8 * 8), s1 = *reinterpret_cast<const v4f *>(sc + c8 * 8 + 4);
+        const v4f b0 = *reinterpret_cast<const v4f *>(bias_int + c8 * 8), b1 = *reinterpret_cast<const v4f *>(bias_int + c8 * 8 + 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { scv[k] = s0[k]; scv[4 + k] = s1[k]; bv[k] = b0[k]; bv[4 + k] = b1[k]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cv[k] = dy[c8 * 8 + k].m * dy[c8 * 8 + k].r;
+    }
+    const double c2 = dy2.m * dy2.r;
+    // ---- rows -> fp32 tile, x = fl(fl(Q*s)/s)
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int r = rr + 16 * i;
+        const long long gr = row0 + r;
+        float v[8];
+        if (gr < rows) {
+            if constexpr (sizeof(XT) == 2) {
+                const v8s t = *reinterpret_cast<const v8s *>(x + gr * CC + c8 * 8);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = requotient_m((float)t[k], s, ys);
+            } else {
+                const v2i t = *reinterpret_cast<const v2i *>(x + gr * CC + c8 * 8);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = requotient_m((float)(int)(signed char)(t[k >> 2] >> (8 * (k & 3))), s, ys);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tile[r * LD + c8 * 8 + k] = v[k];
+    }
+    __syncthreads();
+    float yv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) yv[k] = cY[c8 * 8 + k];
+    // ---- per token: the two sums in torch's order for a token-contiguous input, integer square root
+    if (tid < LNT8_ROWS) {
+        const long long row = row0 + tid;
+        const float *xr = tile + tid * LD;
+        float mean = 0.f, F = 0.f;
+        if (row < rows) {
+            const bool ilp4 = (row % L) >= (L / 32) * 32;
+            const float sum = strided_order_sum(xr, CC, ilp4, false, 0.f);
+            mean = rintf(sum / (float)CC);
+            const float var = strided_order_sum(xr, CC, ilp4, true, mean);
+            float k = 65536.0f;
+            for (int n = 0; n < 10; ++n) {
+                const float kn = floorf((k + floorf(var / k)) * 0.5f);
+                if (kn == k) break;
+                k = kn;
+            }
+            F = floorf((1.0f / k) * 2147483648.0f);
+        }
+        rMean[tid] = mean;
+        rF[tid] = F;
+    }
+    __syncthreads();
+    // ---- normalise, requotient by the channel scale, requant(s), store
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int r = rr + 16 * i;
+        const long long gr = row0 + r;
+        if (gr >= rows) continue;
+        const float mean = rMean[r], F = rF[r];
+        int o[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float y = tile[r * LD + c8 * 8 + k] - mean;
+            const float yi = floorf((y * F) * 0.5f);
+            const float zv = rintf(requotient_m(yi + bv[k], scv[k], yv[k]));
+            if (OUTM == 1) o[k] = rq_c((double)zv, cv[k], -128, 127);
+            else o[k] = rq_c((double)rq_c((double)zv, cv[k], -32768, 32767), c2, -32768, 32767);
+        }
+        if (OUTM == 1) {
+            v2i w;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+                w[d] = (o[4 * d] & 0xff) | ((o[4 * d + 1] & 0xff) << 8) | ((o[4 * d + 2] & 0xff) << 16) | (o[4 * d + 3] << 24);
+            *reinterpret_cast<v2i *>(reinterpret_cast<int8_t *>(out) + gr * CC + c8 * 8) = w;
+        } else {
+            v4i w;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) w[d] = (o[2 * d] & 0xffff) | (o[2 * d + 1] << 16);
+            *reinterpret_cast<v4i *>(reinterpret_cast<int16_t *>(out) + gr * CC + c8 * 8) = w;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // a12 fused windowed attention (WindowAttention.forward, swin_quant.py:121-169, between the qkv
 // QuantAct and proj), window 7x7 (N = 49 tokens), head dim 32.  One wavefront per (image, window,

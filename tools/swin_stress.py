@@ -1,0 +1,25 @@
+"""GPU stress: Swin-T b256 through the native runner, unsliced vs sliced vs hipGraph, repeated; reports mismatching runs.
+   python tools/swin_stress.py [runs] [slice counts, comma separated]"""
+import sys, os
+import numpy as np, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from conftest import load_golden, golden_scales
+import ivit_amd as iv
+from ivit_amd.swin_engine import SwinEngine
+g = load_golden("swin_tiny_b1.npz")
+cfg = iv.SWIN_CONFIGS[str(g["cfg_name"])]
+eng = SwinEngine(cfg, iv.make_swin_weights(cfg, int(g["seed"])), golden_scales(g))
+B = 256
+imgs = np.concatenate([iv.make_images_int8(cfg, 1, int(g["images_seed"])), iv.make_images_int8(cfg, B - 1, seed=11)])
+d = torch.from_numpy(imgs).cuda()
+ref = eng.forward(d).clone().cpu().numpy()
+print("golden prefix ok:", np.array_equal(ref[:1], g["logits_int"]))
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+for ns in [int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "4").split(",")]:
+    bad, where = 0, []
+    for i in range(n):
+        o = (eng.forward_ops(d, nslices=ns) if os.environ.get("STRESS_OPS") else eng.forward(d, nslices=ns)).cpu().numpy()
+        if not np.array_equal(o, ref):
+            bad += 1
+            where += list(np.nonzero((o != ref).any(1))[0])
+    print(f"nslices {ns}: {bad} of {n} runs differ; images: {sorted(where)}")
