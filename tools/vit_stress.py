@@ -5,11 +5,11 @@ import numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from conftest import load_golden, golden_scales
 import ivit_amd as iv
-g = load_golden("deit_small_b4.npz")
+g = load_golden(os.environ.get("STRESS_GOLDEN", "deit_small_b4.npz"))
 cfg = iv.CONFIGS[str(g["cfg_name"])]
 from ivit_amd.engine import ViTEngine
 eng = ViTEngine.from_float(cfg, iv.make_vit_weights(cfg, int(g["seed"])), golden_scales(g))
-B = 256
+B = int(os.environ.get("STRESS_BATCH", "256"))
 imgs = np.concatenate([iv.make_images_int8(cfg, int(g["batch"]), int(g["images_seed"])), iv.make_images_int8(cfg, B - int(g["batch"]), seed=11)])
 d = torch.from_numpy(imgs).cuda()
 ref = eng.forward(d).clone().cpu().numpy()
