@@ -575,3 +575,95 @@ int ivit_cpu_mlp_fused_planned(ivit_handle h, ivit_mlp_plan p, const int8_t *x, 
     return ivit_cpu_mlp_fused(h, x, pl->fc1->w, pl->fc1->bias, pl->fc1->dy, gelu_table, pl->fc2->w, pl->fc2->bias, pl->fc2->dy,
                               dy_main, dy_res, residual, out, M, pl->fc1->K, pl->fc1->N);
 }
+
+/* ---- N3: the uint8 front end (utils/data_utils.py:82-91).  Same fp32 operation order as the device kernels and as
+ * oracle/oracle.py::resize_center_crop_u8 (which tests/golden/resize.npz pins against torch's antialiased bicubic). */
+int ivit_cpu_normalize_quantize_u8(ivit_handle h, const uint8_t *hwc, int B, int H, int W, const float mean_host[3],
+                                   const float std_host[3], float scale, int8_t *nchw) {
+    (void)h;
+    TW_REQ(hwc && nchw && mean_host && std_host && B > 0 && H > 0 && W > 0 && scale > 0.f);
+    TW_REQ(std_host[0] != 0.f && std_host[1] != 0.f && std_host[2] != 0.f);
+    const volatile float inv = 1.0f / scale;
+    const int64_t HW = (int64_t)H * W;
+    for (int64_t b = 0; b < B; ++b)
+        for (int64_t p = 0; p < HW; ++p)
+            for (int c = 0; c < 3; ++c) {
+                volatile float v = (float)hwc[(b * HW + p) * 3 + c] / 255.0f;     /* ToTensor */
+                v = v - mean_host[c];                                             /* Normalize */
+                v = v / std_host[c];
+                float r = rintf(inv * v);                                         /* input QuantAct (quant_utils.py:12-48) */
+                r = r < -128.f ? -128.f : (r > 127.f ? 127.f : r);
+                nchw[(b * 3 + c) * HW + p] = (int8_t)(int)r;
+            }
+    return TW_OK;
+}
+
+static float tw_cubic_aa(float x) {
+    const float a = -0.5f;
+    x = fabsf(x);
+    if (x < 1.0f) return ((a + 2.0f) * x - (a + 3.0f)) * x * x + 1.0f;
+    if (x < 2.0f) return (((a * x) - (5.0f * a)) * x + (8.0f * a)) * x - (4.0f * a);
+    return 0.0f;
+}
+typedef struct { int xmin, xsize; float center, invscale, total; } tw_taps;
+static tw_taps tw_aa_taps(int i, int in_size, int out_size) {
+    tw_taps t;
+    const float scale = (float)in_size / (float)out_size;
+    const float support = scale >= 1.0f ? 2.0f * scale : 2.0f;
+    t.invscale = scale >= 1.0f ? 1.0f / scale : 1.0f;
+    t.center = scale * ((float)i + 0.5f);
+    int lo = (int)(t.center - support + 0.5f), hi = (int)(t.center + support + 0.5f);
+    t.xmin = lo > 0 ? lo : 0;
+    t.xsize = (hi < in_size ? hi : in_size) - t.xmin;
+    float tot = 0.0f;
+    for (int j = 0; j < t.xsize; ++j) tot += tw_cubic_aa(((float)(j + t.xmin) - t.center + 0.5f) * t.invscale);
+    t.total = tot;
+    return t;
+}
+static float tw_tap_w(const tw_taps *t, int j) {
+    return tw_cubic_aa(((float)(j + t->xmin) - t->center + 0.5f) * t->invscale) / t->total;
+}
+int ivit_cpu_resize_center_crop_u8(ivit_handle h, const uint8_t *hwc, int B, int H0, int W0, int size, int crop,
+                                   float *workspace, uint8_t *out_hwc) {
+    (void)h;
+    TW_REQ(hwc && workspace && out_hwc && B > 0 && H0 > 0 && W0 > 0 && size > 0 && crop > 0);
+    int Hr, Wr;
+    if (H0 <= W0) { Hr = size; Wr = (int)((int64_t)size * W0 / H0); }
+    else { Wr = size; Hr = (int)((int64_t)size * H0 / W0); }
+    TW_REQ(crop <= Hr && crop <= Wr);
+    const int top = (int)rint((Hr - crop) / 2.0), left = (int)rint((Wr - crop) / 2.0);
+    for (int xo = 0; xo < crop; ++xo) {                       /* horizontal pass, cropped columns only */
+        const tw_taps t = tw_aa_taps(xo + left, W0, Wr);
+        for (int64_t by = 0; by < (int64_t)B * H0; ++by) {
+            const uint8_t *row = hwc + (by * W0 + t.xmin) * 3;
+            float w = tw_tap_w(&t, 0);
+            float a0 = (float)row[0] * w, a1 = (float)row[1] * w, a2 = (float)row[2] * w;
+            for (int j = 1; j < t.xsize; ++j) {
+                w = tw_tap_w(&t, j);
+                a0 += (float)row[j * 3] * w; a1 += (float)row[j * 3 + 1] * w; a2 += (float)row[j * 3 + 2] * w;
+            }
+            float *o = workspace + (by * crop + xo) * 3;
+            o[0] = a0; o[1] = a1; o[2] = a2;
+        }
+    }
+    const int64_t rs = (int64_t)crop * 3;
+    for (int yo = 0; yo < crop; ++yo) {                       /* vertical pass, rne, clamp */
+        const tw_taps t = tw_aa_taps(yo + top, H0, Hr);
+        for (int64_t b = 0; b < B; ++b)
+            for (int xo = 0; xo < crop; ++xo) {
+                const float *col = workspace + ((b * H0 + t.xmin) * crop + xo) * 3;
+                float w = tw_tap_w(&t, 0);
+                float a0 = col[0] * w, a1 = col[1] * w, a2 = col[2] * w;
+                for (int j = 1; j < t.xsize; ++j) {
+                    w = tw_tap_w(&t, j);
+                    a0 += col[j * rs] * w; a1 += col[j * rs + 1] * w; a2 += col[j * rs + 2] * w;
+                }
+                uint8_t *o = out_hwc + ((b * crop + yo) * crop + xo) * 3;
+                const float r0 = rintf(a0), r1 = rintf(a1), r2 = rintf(a2);
+                o[0] = (uint8_t)(int)(r0 < 0.f ? 0.f : (r0 > 255.f ? 255.f : r0));
+                o[1] = (uint8_t)(int)(r1 < 0.f ? 0.f : (r1 > 255.f ? 255.f : r1));
+                o[2] = (uint8_t)(int)(r2 < 0.f ? 0.f : (r2 > 255.f ? 255.f : r2));
+            }
+    }
+    return TW_OK;
+}

@@ -207,13 +207,24 @@ def _cases(rng):
     for sh in (0, 3):
         cs.append(("window_attention_fused", [I(qkvw), dyv(dwq), dyv(dwa), I(relb), 0.06, dyv(dwp), O(np.zeros((Bw, Rw * Rw, Hw * 32), np.int8)),
                                               Bw, Rw, 7, sh, Hw, 32]))
+    # ---- the uint8 front end (N3): ToTensor -> Normalize -> input QuantAct; antialiased bicubic resize + centre crop
+    u8 = rng.integers(0, 256, (2, 37, 53, 3), dtype=np.uint8)
+    u8.reshape(-1)[:256] = np.arange(256, dtype=np.uint8)
+    mean, std = np.array([0.485, 0.456, 0.406], np.float32), np.array([0.229, 0.224, 0.225], np.float32)
+    cs.append(("normalize_quantize_u8", [I(u8), 2, 37, 53, ("host", mean), ("host", std), 0.0207, O(np.zeros((2, 3, 37, 53), np.int8))]))
+    big = rng.integers(0, 256, (2, 60, 83, 3), dtype=np.uint8)
+    cs.append(("resize_center_crop_u8", [I(big), 2, 60, 83, 40, 32, O(np.zeros((2, 60, 32, 3), np.float32)), O(np.zeros((2, 32, 32, 3), np.uint8))]))
+    tall = rng.integers(0, 256, (1, 75, 50, 3), dtype=np.uint8)                        # portrait, upscaling
+    cs.append(("resize_center_crop_u8", [I(tall), 1, 75, 50, 64, 56, O(np.zeros((1, 75, 56, 3), np.float32)), O(np.zeros((1, 56, 56, 3), np.uint8))]))
     return cs
 
 
 def _run(fn, handle, args, to_ptr):
     outs, call = [], [handle]
     for a in args:
-        if isinstance(a, tuple):
+        if isinstance(a, tuple) and a[0] == "host":          # a HOST array on both sides (mean / std of the normalisation)
+            call.append(a[1].ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+        elif isinstance(a, tuple):
             buf = to_ptr(a[1], a[0] == "out")
             call.append(buf[0])
             if a[0] == "out":
@@ -351,3 +362,32 @@ def test_twin_composites_match_the_oracle_chain(twin):
     t = orc.requant(orc.linear_i8(g8, w2, b2), orc.dyadic(s2, s_t), 16)
     ref = orc.requant(t, orc.dyadic(s_t, s_fin), 16, res.astype(np.int32), orc.dyadic(s_res, s_fin))
     assert np.array_equal(out.astype(np.int32), ref)
+
+
+def test_twin_front_end_matches_oracle_and_torch(twin):
+    """N3 twins on the CPU: ivit_cpu_resize_center_crop_u8 == oracle.resize_center_crop_u8 (the restatement that
+    tests/golden/resize.npz pins to torch's antialiased bicubic) on every fixture case; ivit_cpu_normalize_quantize_u8 == the
+    ToTensor -> Normalize -> QuantAct chain in torch fp32 for every pixel value."""
+    import torch
+    from oracle import oracle as orc
+    from conftest import load_golden
+    g = load_golden("resize.npz")
+    for ci in range(int(g["n"])):
+        size, crop = [int(v) for v in g[f"cfg/{ci}"]]
+        img = np.ascontiguousarray(g[f"in/{ci}"])
+        B, H0, W0, _ = img.shape
+        ws, out = np.zeros((B, H0, crop, 3), np.float32), np.zeros((B, crop, crop, 3), np.uint8)
+        assert twin.ivit_cpu_resize_center_crop_u8(None, hp(img), B, H0, W0, size, crop, hp(ws), hp(out)) == 0
+        assert np.array_equal(out, orc.resize_center_crop_u8(img, size, crop)), ci
+    rng = np.random.default_rng(3)
+    u = rng.integers(0, 256, (2, 19, 23, 3), dtype=np.uint8)
+    u.reshape(-1)[:256] = np.arange(256, dtype=np.uint8)
+    mean, std, scale = np.array([0.485, 0.456, 0.406], np.float32), np.array([0.229, 0.224, 0.225], np.float32), 0.0207
+    q = np.zeros((2, 3, 19, 23), np.int8)
+    fp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+    assert twin.ivit_cpu_normalize_quantize_u8(None, hp(u), 2, 19, 23, fp(mean), fp(std), scale, hp(q)) == 0
+    t = torch.from_numpy(u).permute(0, 3, 1, 2).float().div(255)
+    x = t.sub(torch.from_numpy(mean).view(1, 3, 1, 1)).div(torch.from_numpy(std).view(1, 3, 1, 1))
+    inv = np.float32(1.0) / np.float32(scale)
+    ref = torch.clamp(torch.round(x * float(inv)), -128, 127).to(torch.int8).numpy()
+    assert np.array_equal(q, ref)
