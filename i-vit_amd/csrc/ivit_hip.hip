@@ -840,8 +840,8 @@ int ivit_layernorm_requant(ivit_handle h, const int16_t *x, int64_t rows, int C,
             // lanes per row = 4 S (measured on DeiT-S b256: S = 1 23.2 us, S = 2 20.1, S = 4 20.2 — shorter per-wave instruction
             // chains and more waves per SIMD beat the cheaper quad-only reduction).  S = 1 is NOT dispatched: under
             // co-residency with GEMM workgroups layernorm_reg_kernel<192, 1> produced sporadic one-LSB differences in a few
-            // adjacent rows (tools/op_stress.py; S = 2 on the same shape: none in 960 launches) — its ISA interleaves
-            // v_pk_add_f32 with v_mov_b32_dpp writes to the packed instruction's source registers
+            // adjacent rows (tools/op_stress.py; S = 2 on the same shape: none in 960 launches); the mechanism is not established
+            // (see ivit_layernorm.h)
             case 96: LNR_LAUNCH(96, 2);        // Swin-T/S stage 0 (token-order sums use their own kernel)
             case 128: LNR_LAUNCH(128, 2);      // Swin-B stage 0
             case 192: LNR_LAUNCH(192, 2);      // DeiT-T, Swin stage 1

@@ -43,11 +43,11 @@ __device__ __forceinline__ float ln_dpp(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
 
-// S = 1 (4 lanes per row, quad_perm broadcasts) is kept for tools/ubench/ln_probe.hip only and MUST NOT be dispatched: its
-// ISA (184 v_pk_*_f32 interleaved with v_mov_b32_dpp, no s_nop between them) returned one-LSB differences in a few adjacent
-// rows in 1-3 % of the launches that shared CUs with GEMM workgroups (tools/op_stress.py, profiles/README.md round 3).  The
-// S = 2 / S = 4 ISAs use v_add_f32_dpp with the compiler's two wait states and no packed fp32, and are clean under the
-// same stress.
+// S = 1 (4 lanes per row, quad_perm broadcasts) is kept for tools/ubench/ln_probe.hip only and MUST NOT be dispatched: it
+// returned one-LSB differences in a few adjacent rows in 1-3 % of the launches that shared CUs with GEMM workgroups
+// (tools/op_stress.py, profiles/README.md round 3).  The mechanism is not established (its ISA interleaves 184 v_pk_*_f32
+// with v_mov_b32_dpp, but that sequence alone does not reproduce it: tools/ubench/dpp_pk_hazard.hip); the S = 2 / S = 4
+// forms are clean under the same stress (960 launches of the same shape, and the whole-model stress runs).
 // 32 rows per block whatever the split: the per-block staging of the channel constants (an fp64 division each) stays ~8 %
 #define LNR_THREADS(S) (128 * (S))
 // timing probes only (tools/ubench/ln_probe.hip): 1 = no output-pass arithmetic, 2 = no second sum, 4 = no Newton loop
