@@ -45,6 +45,51 @@ def _dy(arr):
     return _lib.Dyadic(float(arr[0, 0]), float(arr[0, 1]))
 
 
+def host_scalars(blob, table):
+    """the by-value entries of a packed blob (host numpy): scalar dyadics and the Shiftmax table metadata"""
+    host = {}
+    for k, (o, dt, shp) in table.items():
+        if dt == "<f8" and shp == (1, 2):
+            host[k] = blob[o:o + 16].view(np.float64).reshape(1, 2).copy()
+        elif k.endswith("exp_meta"):
+            host[k] = blob[o:o + 12].view(np.int32).copy()
+    return host
+
+
+def vit_native_params(cfg, table, f32, host, base):
+    """(ivit_vit_config, ivit_vit_params, keep-alive) for ivit_vit_create — or for its CPU twin: `base` is the address of
+    the packed constants blob, in device memory for the library, in host memory for oracle/ivit_twin.c"""
+    L = _lib
+    ptr = lambda name: base + table[name][0]
+    dy = lambda name: _dy(host[name])
+    blocks = (L.VitBlock * cfg.depth)()
+    for i in range(cfg.depth):
+        p, b = f"blocks.{i}.", blocks[i]
+        b.s_ln1, b.n1_bias_int, b.n1_sc, b.n1_dy = f32[p + "ln1.s"], ptr(p + "norm1.bias_int"), ptr(p + "norm1.sc"), ptr(p + "norm1.dy")
+        b.qkv_w, b.qkv_b, b.qkv_dy = ptr(p + "attn.qkv.w"), ptr(p + "attn.qkv.b"), ptr(p + "attn.qkv.dy")
+        b.dy_qk, b.s_softmax, b.dy_pv = dy(p + "attn.dy_qk"), f32[p + "attn.s_softmax"], dy(p + "attn.dy_pv")
+        if p + "attn.exp_meta" in host:        # Shiftmax tables for this layer's scale
+            meta = host[p + "attn.exp_meta"]
+            b.exp_aq, b.exp_t, b.exp_cls = ptr(p + "attn.exp_aq"), ptr(p + "attn.exp_t"), ptr(p + "attn.exp_cls")
+            b.exp_nc, b.exp_tcount, b.exp_dmin = int(meta[0]), int(meta[1]), int(meta[2])
+        b.proj_w, b.proj_b, b.proj_dy = ptr(p + "attn.proj.w"), ptr(p + "attn.proj.b"), ptr(p + "attn.proj.dy")
+        b.res1_main, b.res1_res = dy(p + "res1.dy_main"), dy(p + "res1.dy_res")
+        b.s_ln2, b.n2_bias_int, b.n2_sc, b.n2_dy = f32[p + "ln2.s"], ptr(p + "norm2.bias_int"), ptr(p + "norm2.sc"), ptr(p + "norm2.dy")
+        b.fc1_w, b.fc1_b, b.fc1_dy = ptr(p + "mlp.fc1.w"), ptr(p + "mlp.fc1.b"), ptr(p + "mlp.fc1.dy")
+        b.s_gelu, b.dy_gelu = f32[p + "mlp.s_gelu"], dy(p + "mlp.dy_gelu")
+        b.fc2_w, b.fc2_b, b.fc2_dy = ptr(p + "mlp.fc2.w"), ptr(p + "mlp.fc2.b"), ptr(p + "mlp.fc2.dy")
+        b.res2_main, b.res2_res = dy(p + "res2.dy_main"), dy(p + "res2.dy_res")
+    prm = L.VitParams()
+    prm.pe_w, prm.pe_b, prm.pe_dy = ptr("patch_embed.proj.w"), ptr("patch_embed.proj.b"), ptr("patch_embed.proj.dy")
+    prm.z_cls, prm.pos, prm.dy_x, prm.dy_pos = ptr("z_cls"), ptr("pos"), dy("embed.dy_x"), dy("embed.dy_pos")
+    prm.blocks_host = ctypes.cast(blocks, ctypes.POINTER(L.VitBlock))
+    prm.s_ln, prm.n_bias_int, prm.n_sc, prm.n_dy = f32["ln.s"], ptr("norm.bias_int"), ptr("norm.sc"), ptr("norm.dy")
+    prm.head_w, prm.head_b = ptr("head.w"), ptr("head.b")
+    c = L.VitConfig(cfg.img_size, cfg.patch_size, cfg.in_chans, cfg.embed_dim, cfg.depth, cfg.num_heads,
+                    cfg.hidden_dim, cfg.num_classes)
+    return c, prm, blocks
+
+
 class ViTEngine:
     def __init__(self, cfg, consts, f32, device="cuda:0", blob=None, table=None):
         """consts/f32 from freeze.freeze_vit (rank 0) — or a pre-packed (blob, table)
@@ -62,17 +107,8 @@ class ViTEngine:
             self.blob = torch.from_numpy(blob).to(self.device)
         else:
             self.blob = blob  # already a device uint8 tensor
-        self.host = {}
         # scalar dyadics are passed by value: keep host copies
-        if isinstance(blob, np.ndarray):
-            hb = blob
-        else:
-            hb = self.blob.cpu().numpy()
-        for k, (o, dt, shp) in table.items():
-            if dt == "<f8" and shp == (1, 2):
-                self.host[k] = hb[o:o + 16].view(np.float64).reshape(1, 2).copy()
-            elif k.endswith("exp_meta"):
-                self.host[k] = hb[o:o + 12].view(np.int32).copy()
+        self.host = host_scalars(blob if isinstance(blob, np.ndarray) else self.blob.cpu().numpy(), table)
         dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.h = _lib.Handle(dev_index, torch.cuda.current_stream(self.device).cuda_stream)
         self._ws = {}
@@ -110,34 +146,7 @@ class ViTEngine:
 
     def _build_native(self):
         """ivit_vit_create: hand the runner device pointers into the blob + host scalars."""
-        cfg, L = self.cfg, _lib
-        ptr = lambda name: self.blob.data_ptr() + self.table[name][0]
-        dy = lambda name: _dy(self.host[name])
-        blocks = (L.VitBlock * cfg.depth)()
-        for i in range(cfg.depth):
-            p, b = f"blocks.{i}.", blocks[i]
-            b.s_ln1, b.n1_bias_int, b.n1_sc, b.n1_dy = self.f32[p + "ln1.s"], ptr(p + "norm1.bias_int"), ptr(p + "norm1.sc"), ptr(p + "norm1.dy")
-            b.qkv_w, b.qkv_b, b.qkv_dy = ptr(p + "attn.qkv.w"), ptr(p + "attn.qkv.b"), ptr(p + "attn.qkv.dy")
-            b.dy_qk, b.s_softmax, b.dy_pv = dy(p + "attn.dy_qk"), self.f32[p + "attn.s_softmax"], dy(p + "attn.dy_pv")
-            if p + "attn.exp_meta" in self.host:        # Shiftmax tables for this layer's scale
-                meta = self.host[p + "attn.exp_meta"]
-                b.exp_aq, b.exp_t, b.exp_cls = ptr(p + "attn.exp_aq"), ptr(p + "attn.exp_t"), ptr(p + "attn.exp_cls")
-                b.exp_nc, b.exp_tcount, b.exp_dmin = int(meta[0]), int(meta[1]), int(meta[2])
-            b.proj_w, b.proj_b, b.proj_dy = ptr(p + "attn.proj.w"), ptr(p + "attn.proj.b"), ptr(p + "attn.proj.dy")
-            b.res1_main, b.res1_res = dy(p + "res1.dy_main"), dy(p + "res1.dy_res")
-            b.s_ln2, b.n2_bias_int, b.n2_sc, b.n2_dy = self.f32[p + "ln2.s"], ptr(p + "norm2.bias_int"), ptr(p + "norm2.sc"), ptr(p + "norm2.dy")
-            b.fc1_w, b.fc1_b, b.fc1_dy = ptr(p + "mlp.fc1.w"), ptr(p + "mlp.fc1.b"), ptr(p + "mlp.fc1.dy")
-            b.s_gelu, b.dy_gelu = self.f32[p + "mlp.s_gelu"], dy(p + "mlp.dy_gelu")
-            b.fc2_w, b.fc2_b, b.fc2_dy = ptr(p + "mlp.fc2.w"), ptr(p + "mlp.fc2.b"), ptr(p + "mlp.fc2.dy")
-            b.res2_main, b.res2_res = dy(p + "res2.dy_main"), dy(p + "res2.dy_res")
-        prm = L.VitParams()
-        prm.pe_w, prm.pe_b, prm.pe_dy = ptr("patch_embed.proj.w"), ptr("patch_embed.proj.b"), ptr("patch_embed.proj.dy")
-        prm.z_cls, prm.pos, prm.dy_x, prm.dy_pos = ptr("z_cls"), ptr("pos"), dy("embed.dy_x"), dy("embed.dy_pos")
-        prm.blocks_host = ctypes.cast(blocks, ctypes.POINTER(L.VitBlock))
-        prm.s_ln, prm.n_bias_int, prm.n_sc, prm.n_dy = self.f32["ln.s"], ptr("norm.bias_int"), ptr("norm.sc"), ptr("norm.dy")
-        prm.head_w, prm.head_b = ptr("head.w"), ptr("head.b")
-        c = L.VitConfig(cfg.img_size, cfg.patch_size, cfg.in_chans, cfg.embed_dim, cfg.depth, cfg.num_heads,
-                        cfg.hidden_dim, cfg.num_classes)
+        c, prm, self._native_keep = vit_native_params(self.cfg, self.table, self.f32, self.host, self.blob.data_ptr())
         self.model = _P()
         self.h._check(self.h.lib.ivit_vit_create(self.h.h, ctypes.byref(c), ctypes.byref(prm), self.MAX_SLICES,
                                                  ctypes.byref(self.model)), "ivit_vit_create")

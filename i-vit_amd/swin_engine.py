@@ -135,6 +135,49 @@ def pack_swin_constants(consts):
     return blob, table, host
 
 
+def swin_host_scalars(host):
+    """(fp32 scalars, by-value dyadics) from the host part of pack_swin_constants"""
+    return ({k: v[1] for k, v in host.items() if v[0] == "f"},
+            {k: _lib.Dyadic(v[1], v[2]) for k, v in host.items() if v[0] == "dy"})
+
+
+def swin_native_params(cfg, table, f, dy, base):
+    """(ivit_swin_config, ivit_swin_params, keep-alive) for ivit_swin_create — or its CPU twin: `base` is the address of the
+    packed constants blob (device memory for the library, host memory for oracle/ivit_twin.c)"""
+    L = _lib
+    a = lambda name: (base + table[name][0]) if name in table else None
+    ln = lambda p: L.LnParams(a(p + ".bias_int"), a(p + ".sc"), a(p + ".dy"))
+    lin = lambda p: L.LinParams(a(p + ".w"), a(p + ".b"), a(p + ".dy"))
+    nb = sum(cfg.depths)
+    blocks = (L.SwinBlock * nb)()
+    merges = (L.SwinMerge * max(1, cfg.num_layers - 1))()
+    i = 0
+    for li, depth in enumerate(cfg.depths):
+        for bj in range(depth):
+            p, b = f"layers.{li}.blocks.{bj}.", blocks[i]
+            b.s_in, b.n1, b.qkv = f[p + "s_in"], ln(p + "norm1"), lin(p + "attn.qkv")
+            b.dy_qk, b.dy_a, b.relb = dy[p + "attn.dy_qk"], dy[p + "attn.dy_a"], a(p + "attn.relb")
+            b.s_softmax, b.dy_pv, b.proj = f[p + "attn.s_softmax"], dy[p + "attn.dy_pv"], lin(p + "attn.proj")
+            b.res1_main, b.res1_res = dy[p + "res1.dy_main"], dy[p + "res1.dy_res"]
+            b.s_mid, b.n2, b.fc1 = f[p + "s_mid"], ln(p + "norm2"), lin(p + "mlp.fc1")
+            b.s_gelu, b.dy_gelu, b.fc2 = f[p + "mlp.s_gelu"], dy[p + "mlp.dy_gelu"], lin(p + "mlp.fc2")
+            b.res2_main, b.res2_res = dy[p + "res2.dy_main"], dy[p + "res2.dy_res"]
+            i += 1
+        if li < cfg.num_layers - 1:
+            p, g = f"layers.{li}.downsample.", merges[li]
+            g.s_in, g.n, g.red = f[p + "s_in"], ln(p + "norm"), lin(p + "reduction")
+    prm = L.SwinParams()
+    prm.pe, prm.s_bn, prm.pn, prm.dy_qact1 = lin("patch_embed.proj"), f["patch_embed.s_bn"], ln("patch_embed.norm"), a("dy_qact1")
+    prm.blocks_host = ctypes.cast(blocks, ctypes.POINTER(L.SwinBlock))
+    prm.merges_host = ctypes.cast(merges, ctypes.POINTER(L.SwinMerge))
+    prm.s_norm_in, prm.n, prm.dy_pool = f["norm.s_in"], ln("norm"), dy["dy_pool"]
+    prm.head_w, prm.head_b = a("head.w"), a("head.b")
+    c = L.SwinConfigC(cfg.img_size, cfg.patch_size, cfg.in_chans, cfg.embed_dim, cfg.num_layers, cfg.window_size,
+                      int(cfg.mlp_ratio), cfg.num_classes, (ctypes.c_int * 4)(*(list(cfg.depths) + [0] * 4)[:4]),
+                      (ctypes.c_int * 4)(*(list(cfg.num_heads) + [0] * 4)[:4]))
+    return c, prm, (blocks, merges)
+
+
 class SwinEngine:
     def __init__(self, cfg, weights, scales, device="cuda:0", packed=None):
         """weights/scales: freeze here (rank 0) — or `packed` = (blob, table, host) received from a broadcast."""
@@ -149,8 +192,7 @@ class SwinEngine:
         self.blob = torch.from_numpy(blob).to(self.device) if isinstance(blob, np.ndarray) else blob.to(self.device)
         o, dt, shp = table["head.scale"]
         self.head_scale = self.blob[o:o + 4 * int(np.prod(shp))].cpu().numpy().view(np.float32).copy()
-        self.f = {k: v[1] for k, v in host.items() if v[0] == "f"}
-        self.dy = {k: _lib.Dyadic(v[1], v[2]) for k, v in host.items() if v[0] == "dy"}
+        self.f, self.dy = swin_host_scalars(host)
         self.t = _BlobView(self.blob, table)
         self.h = _lib.Handle(self.device.index if self.device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(self.device).cuda_stream)
         self._build_native()
@@ -175,37 +217,7 @@ class SwinEngine:
 
     def _build_native(self):
         """ivit_swin_create: device pointers into the blob + host scalars -> one C call per batch"""
-        cfg, L, f, dy = self.cfg, _lib, self.f, self.dy
-        a = lambda name: self.t.addr(name) if name in self.table else None
-        ln = lambda p: L.LnParams(a(p + ".bias_int"), a(p + ".sc"), a(p + ".dy"))
-        lin = lambda p: L.LinParams(a(p + ".w"), a(p + ".b"), a(p + ".dy"))
-        nb = sum(cfg.depths)
-        blocks = (L.SwinBlock * nb)()
-        merges = (L.SwinMerge * max(1, cfg.num_layers - 1))()
-        i = 0
-        for li, depth in enumerate(cfg.depths):
-            for bj in range(depth):
-                p, b = f"layers.{li}.blocks.{bj}.", blocks[i]
-                b.s_in, b.n1, b.qkv = f[p + "s_in"], ln(p + "norm1"), lin(p + "attn.qkv")
-                b.dy_qk, b.dy_a, b.relb = dy[p + "attn.dy_qk"], dy[p + "attn.dy_a"], a(p + "attn.relb")
-                b.s_softmax, b.dy_pv, b.proj = f[p + "attn.s_softmax"], dy[p + "attn.dy_pv"], lin(p + "attn.proj")
-                b.res1_main, b.res1_res = dy[p + "res1.dy_main"], dy[p + "res1.dy_res"]
-                b.s_mid, b.n2, b.fc1 = f[p + "s_mid"], ln(p + "norm2"), lin(p + "mlp.fc1")
-                b.s_gelu, b.dy_gelu, b.fc2 = f[p + "mlp.s_gelu"], dy[p + "mlp.dy_gelu"], lin(p + "mlp.fc2")
-                b.res2_main, b.res2_res = dy[p + "res2.dy_main"], dy[p + "res2.dy_res"]
-                i += 1
-            if li < cfg.num_layers - 1:
-                p, g = f"layers.{li}.downsample.", merges[li]
-                g.s_in, g.n, g.red = f[p + "s_in"], ln(p + "norm"), lin(p + "reduction")
-        prm = L.SwinParams()
-        prm.pe, prm.s_bn, prm.pn, prm.dy_qact1 = lin("patch_embed.proj"), f["patch_embed.s_bn"], ln("patch_embed.norm"), a("dy_qact1")
-        prm.blocks_host = ctypes.cast(blocks, ctypes.POINTER(L.SwinBlock))
-        prm.merges_host = ctypes.cast(merges, ctypes.POINTER(L.SwinMerge))
-        prm.s_norm_in, prm.n, prm.dy_pool = f["norm.s_in"], ln("norm"), dy["dy_pool"]
-        prm.head_w, prm.head_b = a("head.w"), a("head.b")
-        c = L.SwinConfigC(cfg.img_size, cfg.patch_size, cfg.in_chans, cfg.embed_dim, cfg.num_layers, cfg.window_size,
-                          int(cfg.mlp_ratio), cfg.num_classes, (ctypes.c_int * 4)(*(list(cfg.depths) + [0] * 4)[:4]),
-                          (ctypes.c_int * 4)(*(list(cfg.num_heads) + [0] * 4)[:4]))
+        c, prm, self._native_keep = swin_native_params(self.cfg, self.table, self.f, self.dy, self.blob.data_ptr())
         self.model = _P()
         self.h._check(self.h.lib.ivit_swin_create(self.h.h, ctypes.byref(c), ctypes.byref(prm), self.MAX_SLICES,
                                                   ctypes.byref(self.model)), "ivit_swin_create")

@@ -667,3 +667,147 @@ int ivit_cpu_resize_center_crop_u8(ivit_handle h, const uint8_t *hwc, int B, int
     }
     return TW_OK;
 }
+
+/* ---- a9-a11: the whole-model runner (VisionTransformer.forward, vit_quant.py:254-282), as the chain of twinned operators
+ * in the order csrc/ivit_model.h::run_slice issues them.  Host pointers in ivit_vit_params / ivit_vit_block; the Shiftmax
+ * tables of a block are ignored (the arithmetic Shiftmax is what they are checked against); slices are a device notion:
+ * any nslices gives the same integers; the workspace is not used. */
+struct ivit_vit_s { ivit_vit_config cfg; ivit_vit_params prm; ivit_vit_block *blocks; };
+int ivit_cpu_vit_create(ivit_handle h, const ivit_vit_config *cfg, const ivit_vit_params *params, int max_slices, ivit_vit *out) {
+    (void)h;
+    TW_REQ(cfg && params && out && params->blocks_host && max_slices >= 1 && cfg->depth > 0 && cfg->num_heads > 0);
+    TW_REQ(cfg->img_size % cfg->patch_size == 0 && cfg->embed_dim % cfg->num_heads == 0);
+    struct ivit_vit_s *m = (struct ivit_vit_s *)xmalloc(sizeof *m);
+    m->cfg = *cfg; m->prm = *params;
+    m->blocks = (ivit_vit_block *)xmalloc(sizeof(ivit_vit_block) * cfg->depth);
+    memcpy(m->blocks, params->blocks_host, sizeof(ivit_vit_block) * cfg->depth);
+    *out = m;
+    return TW_OK;
+}
+int ivit_cpu_vit_destroy(ivit_vit m) { if (!m) return TW_INVALID; free(m->blocks); free(m); return TW_OK; }
+int ivit_cpu_vit_workspace_bytes(ivit_vit m, int batch, int nslices, size_t *bytes) {
+    TW_REQ(m && bytes && batch > 0 && nslices >= 1 && nslices <= batch);
+    *bytes = 256;
+    return TW_OK;
+}
+int ivit_cpu_vit_workspace_init(ivit_vit m, void *workspace, size_t bytes, int batch, int nslices) {
+    TW_REQ(m && workspace && bytes >= 256 && batch > 0 && nslices >= 1);
+    return TW_OK;
+}
+int ivit_cpu_vit_forward(ivit_vit m, const int8_t *images, int batch, int nslices, void *workspace, size_t bytes, int32_t *logits) {
+    (void)workspace; (void)bytes;
+    TW_REQ(m && images && logits && batch > 0 && nslices >= 1 && nslices <= batch);
+    const ivit_vit_config *c = &m->cfg;
+    const ivit_vit_params *P = &m->prm;
+    const int g = c->img_size / c->patch_size, np_ = g * g, T = np_ + 1, D = c->embed_dim, H = c->num_heads, dh = D / H;
+    const int Hd = c->hidden_dim, ld = (T + 15) / 16 * 16, Kp = c->in_chans * c->patch_size * c->patch_size, B = batch;
+    const int64_t M = (int64_t)B * T;
+    int8_t *patches = (int8_t *)xmalloc((size_t)B * np_ * Kp), *a8 = (int8_t *)xmalloc((size_t)M * D);
+    int8_t *q = (int8_t *)xmalloc((size_t)M * D), *k = (int8_t *)xmalloc((size_t)M * D);
+    int8_t *vt = (int8_t *)calloc((size_t)B * H * dh * ld, 1), *ctx8 = (int8_t *)xmalloc((size_t)M * D);
+    int8_t *h8 = (int8_t *)xmalloc((size_t)M * Hd), *g8 = (int8_t *)xmalloc((size_t)M * Hd), *cls8 = (int8_t *)xmalloc((size_t)B * D);
+    int16_t *patch16 = (int16_t *)xmalloc((size_t)B * np_ * D * 2), *x = (int16_t *)xmalloc((size_t)M * D * 2), *y = (int16_t *)xmalloc((size_t)M * D * 2);
+    int rc = TW_OK;
+#define TW_RUN(call) do { if (rc == TW_OK) rc = (call); } while (0)
+    TW_RUN(ivit_cpu_im2col_patch(NULL, images, B, c->in_chans, c->img_size, c->img_size, c->patch_size, patches));
+    TW_RUN(ivit_cpu_linear_i8_requant(NULL, patches, P->pe_w, P->pe_b, P->pe_dy, 16, patch16, B * np_, D, Kp));
+    TW_RUN(ivit_cpu_embed_finish(NULL, patch16, P->z_cls, P->pos, P->dy_x, P->dy_pos, x, B, T, D));
+    for (int i = 0; i < c->depth; ++i) {
+        const ivit_vit_block *b = &m->blocks[i];
+        TW_RUN(ivit_cpu_layernorm_requant(NULL, x, M, D, D, b->s_ln1, b->n1_bias_int, b->n1_sc, b->n1_dy, a8));
+        TW_RUN(ivit_cpu_linear_i8_qkv(NULL, a8, b->qkv_w, b->qkv_b, b->qkv_dy, q, k, vt, B, T, H, dh, ld));
+        TW_RUN(ivit_cpu_attention_fused(NULL, q, k, vt, b->dy_qk, b->s_softmax, b->dy_pv, ctx8, B, H, T, dh, ld));
+        TW_RUN(ivit_cpu_linear_i8_requant_residual(NULL, ctx8, b->proj_w, b->proj_b, b->proj_dy, b->res1_main, b->res1_res, x, y, (int)M, D, D));
+        { int16_t *t = x; x = y; y = t; }
+        TW_RUN(ivit_cpu_layernorm_requant(NULL, x, M, D, D, b->s_ln2, b->n2_bias_int, b->n2_sc, b->n2_dy, a8));
+        TW_RUN(ivit_cpu_linear_i8_requant(NULL, a8, b->fc1_w, b->fc1_b, b->fc1_dy, 8, h8, (int)M, Hd, D));
+        TW_RUN(ivit_cpu_shiftgelu_requant(NULL, h8, M, Hd, b->s_gelu, b->dy_gelu, g8));
+        TW_RUN(ivit_cpu_linear_i8_requant_residual(NULL, g8, b->fc2_w, b->fc2_b, b->fc2_dy, b->res2_main, b->res2_res, x, y, (int)M, D, Hd));
+        { int16_t *t = x; x = y; y = t; }
+    }
+    /* final norm on the class-token rows only (row stride T*D), then the head's int32 accumulators */
+    TW_RUN(ivit_cpu_layernorm_requant(NULL, x, B, D, (int64_t)T * D, P->s_ln, P->n_bias_int, P->n_sc, P->n_dy, cls8));
+    TW_RUN(ivit_cpu_linear_i8(NULL, cls8, P->head_w, P->head_b, logits, B, c->num_classes, D));
+    free(patches); free(a8); free(q); free(k); free(vt); free(ctx8); free(h8); free(g8); free(cls8); free(patch16); free(x); free(y);
+    return rc;
+}
+
+/* ---- a12: SwinTransformer.forward (swin_quant.py:539-564) as csrc/ivit_model.h::swin_run_slice chains the operators */
+struct ivit_swin_s { ivit_swin_config cfg; ivit_swin_params prm; ivit_swin_block *blocks; ivit_swin_merge *merges; int nblocks; ivit_dyadic dy_qact1; };
+int ivit_cpu_swin_create(ivit_handle h, const ivit_swin_config *cfg, const ivit_swin_params *params, int max_slices, ivit_swin *out) {
+    (void)h;
+    TW_REQ(cfg && params && out && params->blocks_host && params->dy_qact1 && max_slices >= 1);
+    TW_REQ(cfg->num_layers >= 1 && cfg->num_layers <= 4 && cfg->window_size == 7);
+    int nb = 0;
+    for (int li = 0; li < cfg->num_layers; ++li) {
+        if (cfg->num_heads[li] <= 0 || ((cfg->embed_dim << li) / cfg->num_heads[li]) != 32) return 3;     /* IVIT_ERR_UNSUPPORTED */
+        nb += cfg->depths[li];
+    }
+    struct ivit_swin_s *m = (struct ivit_swin_s *)xmalloc(sizeof *m);
+    m->cfg = *cfg; m->prm = *params; m->nblocks = nb; m->dy_qact1 = params->dy_qact1[0];
+    m->blocks = (ivit_swin_block *)xmalloc(sizeof(ivit_swin_block) * nb);
+    memcpy(m->blocks, params->blocks_host, sizeof(ivit_swin_block) * nb);
+    m->merges = (ivit_swin_merge *)xmalloc(sizeof(ivit_swin_merge) * (cfg->num_layers > 1 ? cfg->num_layers - 1 : 1));
+    if (cfg->num_layers > 1) memcpy(m->merges, params->merges_host, sizeof(ivit_swin_merge) * (cfg->num_layers - 1));
+    *out = m;
+    return TW_OK;
+}
+int ivit_cpu_swin_destroy(ivit_swin m) { if (!m) return TW_INVALID; free(m->blocks); free(m->merges); free(m); return TW_OK; }
+int ivit_cpu_swin_workspace_bytes(ivit_swin m, int batch, int nslices, size_t *bytes) {
+    TW_REQ(m && bytes && batch > 0 && nslices >= 1 && nslices <= batch);
+    *bytes = 256;
+    return TW_OK;
+}
+int ivit_cpu_swin_forward(ivit_swin m, const int8_t *images, int batch, int nslices, void *workspace, size_t bytes, int32_t *logits) {
+    (void)workspace; (void)bytes;
+    TW_REQ(m && images && logits && batch > 0 && nslices >= 1 && nslices <= batch);
+    const ivit_swin_config *c = &m->cfg;
+    const ivit_swin_params *P = &m->prm;
+    const int E = c->embed_dim, B = batch, Kp = c->in_chans * c->patch_size * c->patch_size;
+    int res = c->img_size / c->patch_size, L = res * res;
+    int64_t M = (int64_t)B * L;
+    const size_t M0 = (size_t)M;
+    int8_t *patches = (int8_t *)xmalloc(M0 * Kp), *a8 = (int8_t *)xmalloc(M0 * E), *qkv = (int8_t *)xmalloc(M0 * 3 * E);
+    int8_t *ctx = (int8_t *)xmalloc(M0 * E), *h8 = (int8_t *)xmalloc(M0 * c->mlp_ratio * E), *g8 = (int8_t *)xmalloc(M0 * c->mlp_ratio * E);
+    int8_t *pool = (int8_t *)xmalloc((size_t)B * (E << (c->num_layers - 1)));
+    int16_t *x = (int16_t *)xmalloc(M0 * E * 2), *y = (int16_t *)xmalloc(M0 * E * 2), *t16 = (int16_t *)xmalloc(M0 * E * 2);
+    int rc = TW_OK;
+    TW_RUN(ivit_cpu_im2col_patch(NULL, images, B, c->in_chans, c->img_size, c->img_size, c->patch_size, patches));
+    TW_RUN(ivit_cpu_linear_i8_requant(NULL, patches, P->pe.w, P->pe.b, P->pe.dy, 8, a8, (int)M, E, Kp));
+    TW_RUN(ivit_cpu_patch_norm_tokenorder(NULL, a8, M, E, P->s_bn, P->pn.bias_int, P->pn.sc, P->pn.dy, m->dy_qact1, L, x));
+    int bi = 0;
+    for (int li = 0; li < c->num_layers; ++li) {
+        const int C = E << li, heads = c->num_heads[li];
+        for (int bj = 0; bj < c->depths[li]; ++bj, ++bi) {
+            const ivit_swin_block *b = &m->blocks[bi];
+            const int shift = (bj % 2 == 0 || res <= c->window_size) ? 0 : c->window_size / 2;
+            if (li == 0) TW_RUN(ivit_cpu_layernorm_tokenorder_requant(NULL, x, M, C, b->s_in, b->n1.bias_int, b->n1.sc, b->n1.dy, L, a8));
+            else TW_RUN(ivit_cpu_layernorm_requant(NULL, x, M, C, C, b->s_in, b->n1.bias_int, b->n1.sc, b->n1.dy, a8));
+            TW_RUN(ivit_cpu_linear_i8_requant(NULL, a8, b->qkv.w, b->qkv.b, b->qkv.dy, 8, qkv, (int)M, 3 * C, C));
+            TW_RUN(ivit_cpu_window_attention_fused(NULL, qkv, b->dy_qk, b->dy_a, b->relb, b->s_softmax, b->dy_pv, ctx, B, res, c->window_size, shift, heads, C / heads));
+            TW_RUN(ivit_cpu_linear_i8_requant_residual(NULL, ctx, b->proj.w, b->proj.b, b->proj.dy, b->res1_main, b->res1_res, x, y, (int)M, C, C));
+            { int16_t *t = x; x = y; y = t; }
+            if (li == 0) TW_RUN(ivit_cpu_layernorm_tokenorder_requant(NULL, x, M, C, b->s_mid, b->n2.bias_int, b->n2.sc, b->n2.dy, L, a8));
+            else TW_RUN(ivit_cpu_layernorm_requant(NULL, x, M, C, C, b->s_mid, b->n2.bias_int, b->n2.sc, b->n2.dy, a8));
+            TW_RUN(ivit_cpu_linear_i8_requant(NULL, a8, b->fc1.w, b->fc1.b, b->fc1.dy, 8, h8, (int)M, c->mlp_ratio * C, C));
+            TW_RUN(ivit_cpu_shiftgelu_requant(NULL, h8, M, c->mlp_ratio * C, b->s_gelu, b->dy_gelu, g8));
+            TW_RUN(ivit_cpu_linear_i8_requant_residual(NULL, g8, b->fc2.w, b->fc2.b, b->fc2.dy, b->res2_main, b->res2_res, x, y, (int)M, C, c->mlp_ratio * C));
+            { int16_t *t = x; x = y; y = t; }
+        }
+        if (li < c->num_layers - 1) {     /* PatchMerging: gather -> LN(4C) -> qact1(8) -> reduction -> qact2(8) */
+            const ivit_swin_merge *g = &m->merges[li];
+            TW_RUN(ivit_cpu_patch_merge_gather(NULL, x, 16, B, res, C, t16));
+            res /= 2; L = res * res; M = (int64_t)B * L;
+            TW_RUN(ivit_cpu_layernorm_requant(NULL, t16, M, 4 * C, 4 * C, g->s_in, g->n.bias_int, g->n.sc, g->n.dy, a8));
+            TW_RUN(ivit_cpu_linear_i8_requant(NULL, a8, g->red.w, NULL, g->red.dy, 8, ctx, (int)M, 2 * C, 4 * C));
+            TW_RUN(ivit_cpu_widen_i8_i16(NULL, ctx, x, M * 2 * C));
+        }
+    }
+    const int Cl = E << (c->num_layers - 1);
+    TW_RUN(ivit_cpu_layernorm_requant(NULL, x, M, Cl, Cl, P->s_norm_in, P->n.bias_int, P->n.sc, P->n.dy, a8));
+    TW_RUN(ivit_cpu_avgpool_requant(NULL, a8, B, L, Cl, P->dy_pool, pool));
+    TW_RUN(ivit_cpu_linear_i8(NULL, pool, P->head_w, P->head_b, logits, B, c->num_classes, Cl));
+    free(patches); free(a8); free(qkv); free(ctx); free(h8); free(g8); free(pool); free(x); free(y); free(t16);
+    return rc;
+}
+#undef TW_RUN

@@ -14,6 +14,7 @@ import pytest
 from conftest import ROOT, load_golden
 
 import ivit_amd as iv
+from conftest import golden_scales
 from ivit_amd import _lib
 
 sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -331,7 +332,10 @@ def test_every_twinned_entry_point_agrees_with_the_hip_library(twin):
     rest = set(gen_twin_header.TWIN) - seen - {"linear_plan_create", "linear_plan_destroy", "linear_plan_query",
                                                 "linear_i8_requant_planned", "linear_i8_requant_residual_planned",
                                                 "linear_i8_qkv_planned", "attention_fused_lut", "shiftgelu_requant_lut", "mlp_fused",
-                                                "mlp_plan_create", "mlp_plan_destroy", "mlp_fused_planned"}
+                                                "mlp_plan_create", "mlp_plan_destroy", "mlp_fused_planned",
+                                                # the whole-model runners: test_twin_runners_agree_with_the_hip_runners
+                                                "vit_create", "vit_destroy", "vit_workspace_bytes", "vit_workspace_init", "vit_forward",
+                                                "swin_create", "swin_destroy", "swin_workspace_bytes", "swin_forward"}
     assert not rest, rest
 
 
@@ -391,3 +395,88 @@ def test_twin_front_end_matches_oracle_and_torch(twin):
     inv = np.float32(1.0) / np.float32(scale)
     ref = torch.clamp(torch.round(x * float(inv)), -128, 127).to(torch.int8).numpy()
     assert np.array_equal(q, ref)
+
+
+def _twin_vit(twin, g, images):
+    """ivit_cpu_vit_create / _forward on host constants packed exactly as ViTEngine packs them for the device"""
+    from ivit_amd import engine as E
+    cfg = iv.CONFIGS[str(g["cfg_name"])]
+    consts, f32 = E.freeze_vit(cfg, iv.make_vit_weights(cfg, int(g["seed"])), golden_scales(g))
+    blob, table = E.pack_constants(consts)
+    f32 = {k: float(np.float32(v)) for k, v in f32.items()}
+    c, prm, keep = E.vit_native_params(cfg, table, f32, E.host_scalars(blob, table), blob.ctypes.data)
+    m = _P()
+    assert twin.ivit_cpu_vit_create(None, ctypes.byref(c), ctypes.byref(prm), 1, ctypes.byref(m)) == 0
+    n = ctypes.c_size_t()
+    B = images.shape[0]
+    assert twin.ivit_cpu_vit_workspace_bytes(m, B, 1, ctypes.byref(n)) == 0
+    ws = np.zeros(n.value, np.uint8)
+    assert twin.ivit_cpu_vit_workspace_init(m, hp(ws), n.value, B, 1) == 0
+    logits = np.zeros((B, cfg.num_classes), np.int32)
+    assert twin.ivit_cpu_vit_forward(m, hp(np.ascontiguousarray(images)), B, 1, hp(ws), n.value, hp(logits)) == 0
+    assert twin.ivit_cpu_vit_destroy(m) == 0
+    return logits
+
+
+def _twin_swin(twin, g, images):
+    from ivit_amd import swin_engine as S
+    cfg = iv.SWIN_CONFIGS[str(g["cfg_name"])]
+    blob, table, host = S.pack_swin_constants(S.freeze_swin(cfg, iv.make_swin_weights(cfg, int(g["seed"])), golden_scales(g)))
+    f, dy = S.swin_host_scalars(host)
+    c, prm, keep = S.swin_native_params(cfg, table, f, dy, blob.ctypes.data)
+    m = _P()
+    assert twin.ivit_cpu_swin_create(None, ctypes.byref(c), ctypes.byref(prm), 1, ctypes.byref(m)) == 0
+    n = ctypes.c_size_t()
+    B = images.shape[0]
+    assert twin.ivit_cpu_swin_workspace_bytes(m, B, 1, ctypes.byref(n)) == 0
+    ws = np.zeros(n.value, np.uint8)
+    logits = np.zeros((B, cfg.num_classes), np.int32)
+    assert twin.ivit_cpu_swin_forward(m, hp(np.ascontiguousarray(images)), B, 1, hp(ws), n.value, hp(logits)) == 0
+    assert twin.ivit_cpu_swin_destroy(m) == 0
+    return logits
+
+
+@pytest.mark.parametrize("fname", ["micro_vit_b2.npz", "micro_vit2h_b3.npz", "deit_tiny_b1.npz", "deit_small_b4.npz"])
+def test_twin_vit_runner_matches_reference_golden(twin, fname):
+    """the whole-model runner's twin (ivit_cpu_vit_*: same structs as ivit_vit_create, host pointers) == the reference's
+    int32 logits, on the CPU"""
+    from conftest import load_golden
+    g = load_golden(fname)
+    cfg = iv.CONFIGS[str(g["cfg_name"])]
+    imgs = iv.make_images_int8(cfg, int(g["batch"]), int(g["images_seed"]))
+    assert np.array_equal(_twin_vit(twin, g, imgs), g["logits_int"])
+
+
+@pytest.mark.parametrize("fname", ["micro_swin_b2.npz", "swin_tiny_b1.npz"])
+def test_twin_swin_runner_matches_reference_golden(twin, fname):
+    from conftest import load_golden
+    g = load_golden(fname)
+    cfg = iv.SWIN_CONFIGS[str(g["cfg_name"])]
+    imgs = iv.make_images_int8(cfg, int(g["batch"]), int(g["images_seed"]))
+    assert np.array_equal(_twin_swin(twin, g, imgs), g["logits_int"])
+
+
+@pytest.mark.gpu
+def test_twin_runners_agree_with_the_hip_runners(twin):
+    """ivit_vit_forward / ivit_swin_forward (device) == ivit_cpu_vit_forward / ivit_cpu_swin_forward (host) on images the
+    goldens do not contain; the device side also sliced"""
+    import torch
+    from conftest import load_golden
+    from ivit_amd.engine import ViTEngine
+    from ivit_amd.swin_engine import SwinEngine
+    g = load_golden("micro_vit2h_b3.npz")
+    cfg = iv.CONFIGS[str(g["cfg_name"])]
+    imgs = iv.make_images_int8(cfg, 7, seed=4242)
+    eng = ViTEngine.from_float(cfg, iv.make_vit_weights(cfg, int(g["seed"])), golden_scales(g))
+    d = torch.from_numpy(imgs).cuda()
+    ref = _twin_vit(twin, g, imgs)
+    assert np.array_equal(eng.forward(d).cpu().numpy(), ref)
+    assert np.array_equal(eng.forward(d, nslices=3).cpu().numpy(), ref)
+    g = load_golden("micro_swin_b2.npz")
+    cfg = iv.SWIN_CONFIGS[str(g["cfg_name"])]
+    imgs = iv.make_images_int8(cfg, 5, seed=4243)
+    eng = SwinEngine(cfg, iv.make_swin_weights(cfg, int(g["seed"])), golden_scales(g))
+    d = torch.from_numpy(imgs).cuda()
+    ref = _twin_swin(twin, g, imgs)
+    assert np.array_equal(eng.forward(d).cpu().numpy(), ref)
+    assert np.array_equal(eng.forward(d, nslices=2).cpu().numpy(), ref)
