@@ -101,6 +101,58 @@ pw = dev(rng.integers(-128, 128, (B, 768), dtype=np.int8)); hw = dev(rng.integer
 stress("ivit_linear_i8 (head)", lambda: torch.empty(B, 1000, dtype=torch.int32, device="cuda"),
        lambda h, o: h.call("ivit_linear_i8", P(pw), P(hw), P(hb), P(o), B, 1000, 768), None)
 
+# ---- the ViT path's kernels (DeiT-S shapes, 32 images): planned GEMMs, fused attention, fused Mlp, front end
+if not os.environ.get("SWIN_ONLY"):
+    Bv, T, D, Hh, Hd = 32, 197, 384, 6, 1536
+    Mv, ldv = Bv * T, 208
+    xa = dev(rng.integers(-128, 128, (Mv, D), dtype=np.int8))
+    def lin(N, K, lo=-5.6, hi=-5.2, so=0.012):
+        w = dev(rng.integers(-128, 128, (N, K), dtype=np.int8)); b = dev(rng.integers(-3000, 3000, N).astype(np.int32))
+        d = dev(iv.freeze.dyadic((10 ** rng.uniform(lo, hi, N)).astype(np.float32), np.float32(so)))
+        pl = _P(); hs[0].call("ivit_linear_plan_create", P(w), P(b), P(d), N, K, ctypes.byref(pl))
+        return (w, b, d), pl
+    keep_q, pq = lin(3 * D, D)
+    stress("ivit_linear_i8_qkv_planned", lambda: torch.zeros(3 * Bv * Hh * 64 * ldv, dtype=torch.int8, device="cuda"),
+           lambda h, o: h.call("ivit_linear_i8_qkv_planned", pq, P(xa), P(o), _P(o.data_ptr() + Bv * Hh * T * 64), _P(o.data_ptr() + 2 * Bv * Hh * T * 64), Bv, T, Hh, 64, ldv), None)
+    keep_p, pp = lin(D, D, -5.9, -5.5, 2e-4)
+    resv = dev(rng.integers(-30000, 30000, (Mv, D)).astype(np.int16))
+    dmv = iv.freeze.dyadic(np.float32(2e-4), np.float32(3.1e-4)); drv = iv.freeze.dyadic(np.float32(2.7e-4), np.float32(3.1e-4))
+    stress("ivit_linear_i8_requant_residual_planned", lambda: torch.empty(Mv, D, dtype=torch.int16, device="cuda"),
+           lambda h, o: h.call("ivit_linear_i8_requant_residual_planned", pp, P(xa), dyv(dmv), dyv(drv), P(resv), P(o), Mv), None)
+    keep_1, p1 = lin(Hd, D)
+    keep_2, p2 = lin(D, Hd, -5.9, -5.5, 2e-4)
+    stress("ivit_linear_i8_requant_planned (fc1)", lambda: torch.empty(Mv, Hd, dtype=torch.int8, device="cuda"),
+           lambda h, o: h.call("ivit_linear_i8_requant_planned", p1, P(xa), 8, P(o), Mv), None)
+    tabv = torch.empty(65536, dtype=torch.int8, device="cuda")
+    hs[0].call("ivit_shiftgelu_build_table", 0.03, dyv(iv.freeze.dyadic(np.float32(0.03 * 2.0 ** -7), np.float32(0.02))), P(tabv))
+    mpv = _P(); hs[0].call("ivit_mlp_plan_create", p1, p2, ctypes.byref(mpv))
+    stress("ivit_mlp_fused_planned", lambda: torch.empty(Mv, D, dtype=torch.int16, device="cuda"),
+           lambda h, o: h.call("ivit_mlp_fused_planned", mpv, P(xa), P(tabv), dyv(dmv), dyv(drv), P(resv), P(o), Mv), None)
+    h8v = dev(rng.integers(-128, 128, (Mv, Hd), dtype=np.int8))
+    stress("ivit_shiftgelu_requant_lut", lambda: torch.empty(Mv, Hd, dtype=torch.int8, device="cuda"),
+           lambda h, o: h.call("ivit_shiftgelu_requant_lut", P(h8v), Mv, Hd, P(tabv), P(o)), None)
+    qv = dev(rng.integers(-128, 128, (Bv * Hh, T, 64), dtype=np.int8)); kv = dev(rng.integers(-128, 128, (Bv * Hh, T, 64), dtype=np.int8))
+    vtn = np.zeros((Bv * Hh, 64, ldv), np.int8); vtn[:, :, :T] = rng.integers(-128, 128, (Bv * Hh, 64, T), dtype=np.int8)
+    vtv = dev(vtn)
+    dqkv, dpvv = iv.freeze.dyadic(np.float32(2e-4), np.float32(6e-2)), iv.freeze.dyadic(np.float32(3e-6), np.float32(9e-3))
+    stress("ivit_attention_fused T=197", lambda: torch.empty(Bv, T, D, dtype=torch.int8, device="cuda"),
+           lambda h, o: h.call("ivit_attention_fused", P(qv), P(kv), P(vtv), dyv(dqkv), 0.06, dyv(dpvv), P(o), Bv, Hh, T, 64, ldv), None)
+    imgv = dev(rng.integers(-128, 128, (Bv, 3, 224, 224), dtype=np.int8))
+    stress("ivit_im2col_patch P=16", lambda: torch.empty(Bv * 196, 768, dtype=torch.int8, device="cuda"),
+           lambda h, o: h.call("ivit_im2col_patch", P(imgv), Bv, 3, 224, 224, 16, P(o)), None)
+    p16v = dev(rng.integers(-20000, 20000, (Bv, T - 1, D)).astype(np.int16)); zc = dev(rng.integers(-10 ** 6, 10 ** 6, D).astype(np.int32))
+    posv = dev(rng.integers(-20000, 20000, (T, D)).astype(np.int16))
+    stress("ivit_embed_finish", lambda: torch.empty(Bv, T, D, dtype=torch.int16, device="cuda"),
+           lambda h, o: h.call("ivit_embed_finish", P(p16v), P(zc), P(posv), dyv(dmv), dyv(drv), P(o), Bv, T, D), None)
+    x96 = dev(rng.integers(-128, 128, (M // 4, 96), dtype=np.int8))
+    w1s = dev(rng.integers(-128, 128, (384, 96), dtype=np.int8)); b1s = dev(rng.integers(-3000, 3000, 384).astype(np.int32))
+    w2s = dev(rng.integers(-128, 128, (96, 384), dtype=np.int8)); b2s = dev(rng.integers(-3000, 3000, 96).astype(np.int32))
+    d1s = dev(iv.freeze.dyadic((10 ** rng.uniform(-5.0, -4.6, 384)).astype(np.float32), np.float32(0.012)))
+    d2s = dev(iv.freeze.dyadic((10 ** rng.uniform(-5.3, -4.9, 96)).astype(np.float32), np.float32(2e-4)))
+    res96 = dev(rng.integers(-30000, 30000, (M // 4, 96)).astype(np.int16))
+    stress("ivit_mlp_fused C=96", lambda: torch.empty(M // 4, 96, dtype=torch.int16, device="cuda"),
+           lambda h, o: h.call("ivit_mlp_fused", P(x96), P(w1s), P(b1s), P(d1s), P(tabv), P(w2s), P(b2s), P(d2s), dyv(dmv), dyv(drv), P(res96), P(o), M // 4, 96, 384), None)
+
 # ---- mixed: every stream walks the operator list (rotated by its index), all streams at once.  MIX_FILTERS="a;b;c" runs
 # one mixed test per filter with only the operators whose name contains it plus the VICTIM operator (name contains MIX_VICTIM)
 def mixed(ops, tag):
