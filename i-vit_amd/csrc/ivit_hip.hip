@@ -549,56 +549,6 @@ struct ivit_mlp_plan_s {
     int device;
 };
 
-// One launch of the fused Mlp kernel over `nseg` token ranges (the runners join their batch slices for this kernel: the
-// unit granularity of the joined ranges is that of the whole batch).  Not exported: ivit_mlp_fused_planned is nseg == 1.
-static int ivit_mlp_fused_segments(ivit_handle h, ivit_mlp_plan p, int nseg, const int8_t *const *x, const int8_t *gelu_table,
-                                   ivit_dyadic dy_main, ivit_dyadic dy_res, const int16_t *const *residual, int16_t *const *out,
-                                   const int64_t *M) {
-    CHECK_H(h);
-    REQUIRE(h, p && x && gelu_table && residual && out && M && nseg >= 1 && nseg <= MLP_MAXSEG, "bad arguments");
-    long long Mtot = 0;
-    for (int s = 0; s < nseg; ++s) {
-        REQUIRE(h, x[s] && residual[s] && out[s] && M[s] > 0, "bad arguments");
-        Mtot += M[s];
-    }
-    MlpArgs a;
-    a.x = x[0]; a.w1f = p->w1f; a.w2f = p->w2f; a.b1 = p->fc1->bias_eff; a.b2 = p->fc2->bias_eff;
-    a.cq1 = p->fc1->cq; a.cq2 = p->fc2->cq; a.tab = gelu_table; a.residual = residual[0]; a.out = out[0];
-    a.cm = dy_main.m * dy_main.r; a.cr = dy_res.m * dy_res.r; a.M = M[0]; a.trace = nullptr; a.nseg = 0;
-    if (!(fabs(a.cm) < RQ_FAST_CLIM && fabs(a.cr) < RQ_FAST_CLIM)) {
-        snprintf(h->err, sizeof(h->err), "ivit_mlp_fused_planned: residual multipliers out of the fast range");
-        return IVIT_ERR_UNSUPPORTED;
-    }
-    const void *fn = p->fma ? (const void *)mlp384_kernel<true> : (const void *)mlp384_kernel<false>;
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_SMEM);
-    if (e != hipSuccess) { snprintf(h->err, sizeof(h->err), "ivit_mlp_fused_planned: attr: %s", hipGetErrorString(e)); return IVIT_ERR_HIP; }
-    // one workgroup per CU.  64-token units round-robin unless cutting contiguous tile ranges into units of <= 5 tiles
-    // saves a whole round (a unit costs a pass over both weight matrices whatever its size)
-    const long long ntiles = (Mtot + 15) / 16, nunits = (ntiles + MLP_TT - 2) / (MLP_TT - 1);
-    unsigned grid = (unsigned)(nunits < h->num_cu ? nunits : h->num_cu);
-    const long long rounds_fixed = (nunits + grid - 1) / grid, rounds_bal = (ntiles + (long long)MLP_TT * grid - 1) / ((long long)MLP_TT * grid);
-    a.balanced = rounds_bal < rounds_fixed;
-    if (nseg > 1) {
-        // workgroups in proportion to the tokens of a range (at least one each), every range cut the balanced way
-        a.nseg = nseg; a.balanced = 1;
-        if (grid < (unsigned)nseg) grid = (unsigned)nseg;
-        unsigned left = grid;
-        long long mleft = Mtot;
-        for (int s = 0; s < nseg; ++s) {
-            unsigned g = s + 1 == nseg ? left : (unsigned)((double)left * (double)M[s] / (double)mleft + 0.5);
-            const unsigned keep = (unsigned)(nseg - 1 - s);           // one workgroup for each range still to come
-            if (g < 1) g = 1;
-            if (g > left - keep) g = left - keep;
-            a.seg_x[s] = x[s]; a.seg_residual[s] = residual[s]; a.seg_out[s] = out[s]; a.seg_M[s] = M[s]; a.seg_g[s] = (int)g;
-            left -= g; mleft -= M[s];
-        }
-    }
-    if (p->fma) mlp384_kernel<true><<<grid, MLP_THREADS, MLP_SMEM, h->stream>>>(a);
-    else mlp384_kernel<false><<<grid, MLP_THREADS, MLP_SMEM, h->stream>>>(a);
-    LAUNCH_CHECK(h);
-    return IVIT_OK;
-}
-
 extern "C" {
 
 int ivit_mlp_plan_create(ivit_handle h, ivit_linear_plan fc1, ivit_linear_plan fc2, ivit_mlp_plan *out) {
@@ -642,7 +592,29 @@ int ivit_mlp_plan_destroy(ivit_mlp_plan p) {
 
 int ivit_mlp_fused_planned(ivit_handle h, ivit_mlp_plan p, const int8_t *x, const int8_t *gelu_table, ivit_dyadic dy_main,
                            ivit_dyadic dy_res, const int16_t *residual, int16_t *out, int64_t M) {
-    return ivit_mlp_fused_segments(h, p, 1, &x, gelu_table, dy_main, dy_res, &residual, &out, &M);
+    CHECK_H(h);
+    REQUIRE(h, p && x && gelu_table && residual && out && M > 0, "bad arguments");
+    MlpArgs a;
+    a.x = x; a.w1f = p->w1f; a.w2f = p->w2f; a.b1 = p->fc1->bias_eff; a.b2 = p->fc2->bias_eff;
+    a.cq1 = p->fc1->cq; a.cq2 = p->fc2->cq; a.tab = gelu_table; a.residual = residual; a.out = out;
+    a.cm = dy_main.m * dy_main.r; a.cr = dy_res.m * dy_res.r; a.M = M; a.trace = nullptr;
+    if (!(fabs(a.cm) < RQ_FAST_CLIM && fabs(a.cr) < RQ_FAST_CLIM)) {
+        snprintf(h->err, sizeof(h->err), "%s: residual multipliers out of the fast range", __func__);
+        return IVIT_ERR_UNSUPPORTED;
+    }
+    const void *fn = p->fma ? (const void *)mlp384_kernel<true> : (const void *)mlp384_kernel<false>;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_SMEM);
+    if (e != hipSuccess) { snprintf(h->err, sizeof(h->err), "%s: attr: %s", __func__, hipGetErrorString(e)); return IVIT_ERR_HIP; }
+    // one workgroup per CU.  64-token units round-robin unless cutting contiguous tile ranges into units of <= 5 tiles
+    // saves a whole round (a unit costs a pass over both weight matrices whatever its size)
+    const long long ntiles = (M + 15) / 16, nunits = (ntiles + MLP_TT - 2) / (MLP_TT - 1);
+    const unsigned grid = (unsigned)(nunits < h->num_cu ? nunits : h->num_cu);
+    const long long rounds_fixed = (nunits + grid - 1) / grid, rounds_bal = (ntiles + (long long)MLP_TT * grid - 1) / ((long long)MLP_TT * grid);
+    a.balanced = rounds_bal < rounds_fixed;
+    if (p->fma) mlp384_kernel<true><<<grid, MLP_THREADS, MLP_SMEM, h->stream>>>(a);
+    else mlp384_kernel<false><<<grid, MLP_THREADS, MLP_SMEM, h->stream>>>(a);
+    LAUNCH_CHECK(h);
+    return IVIT_OK;
 }
 
 }  // extern "C"

@@ -42,7 +42,6 @@
 #define MLP_STAB (MLP_SA + MLP_KS1 * MLP_KBLK)    // one ShiftGELU table line (256 B) per half-wave
 #define MLP_SMEM (MLP_STAB + 2 * MLP_WAVES * 256)
 #define MLP_MAGIC 6755399441055744.0
-#define MLP_MAXSEG 8
 // timeline instrumentation (tools/ubench/mlp_probe.hip, -DMLP_TRACE=1): every wave of workgroup 0 stamps s_memtime at the
 // phase boundaries of its first units into p.trace[(unit_index * 8 + wave) * 8 + point]
 #ifndef MLP_TRACE
@@ -64,15 +63,6 @@ struct MlpArgs {
     int16_t *out;             // [M, 384]
     double cm, cr;            // qact4: main and identity multipliers
     long long M;
-    // Several token ranges in ONE launch (the runners' batch slices, joined for this kernel: a slice of 128 images is 98 tokens
-    // per CU = two half-empty units, the joined 256 are three full ones).  nseg == 0: the single range above.  Workgroups
-    // [sum g[0..s), sum g[0..s]) belong to segment s and split ITS tiles among themselves.
-    int nseg;
-    const int8_t *seg_x[MLP_MAXSEG];
-    const int16_t *seg_residual[MLP_MAXSEG];
-    int16_t *seg_out[MLP_MAXSEG];
-    long long seg_M[MLP_MAXSEG];
-    int seg_g[MLP_MAXSEG];
     int balanced;             // unit schedule: 0 = 64-token units dealt round-robin, 1 = contiguous tile ranges cut into units of <= 5 tiles
     unsigned long long *trace;   // MLP_TRACE builds only
 };
@@ -130,27 +120,17 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES / 4) void mlp384_kernel(MlpA
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     typedef double v2d __attribute__((ext_vector_type(2)));
 
-    // ---- this workgroup's token range (segment), then its units: (first tile, tiles) of unit i
-    int wg = blockIdx.x, nwg = gridDim.x;
-    const int8_t *X = p.x;
-    const int16_t *RES = p.residual;
-    int16_t *OUT = p.out;
-    long long MM = p.M;
-    if (p.nseg > 0) {
-        int sgm = 0;
-        while (sgm + 1 < p.nseg && wg >= p.seg_g[sgm]) { wg -= p.seg_g[sgm]; ++sgm; }
-        X = p.seg_x[sgm]; RES = p.seg_residual[sgm]; OUT = p.seg_out[sgm]; MM = p.seg_M[sgm]; nwg = p.seg_g[sgm];
-    }
-    const long long ntiles = (MM + 15) >> 4;
-    const long long t_beg = ntiles * wg / nwg, t_end = ntiles * (wg + 1) / nwg;
+    // ---- this workgroup's units: (first tile, tiles) of unit i
+    const long long ntiles = (p.M + 15) >> 4;
+    const long long t_beg = ntiles * blockIdx.x / gridDim.x, t_end = ntiles * (blockIdx.x + 1) / gridDim.x;
     const int n_own = (int)(t_end - t_beg);
     const long long nfix = (ntiles + MLP_TT - 2) / (MLP_TT - 1);                 // 64-token units
     const int nu = p.balanced ? (n_own + MLP_TT - 1) / MLP_TT
-                              : (int)((nfix - (long long)wg + nwg - 1) / nwg);
+                              : (int)((nfix - (long long)blockIdx.x + gridDim.x - 1) / gridDim.x);
     if (nu <= 0) return;
     auto unit_tile0 = [&](int i) -> long long {
         if (p.balanced) return t_beg + (long long)n_own * i / nu;
-        return min(((long long)wg + (long long)i * nwg) * (MLP_TT - 1), ntiles);
+        return min(((long long)blockIdx.x + (long long)i * gridDim.x) * (MLP_TT - 1), ntiles);
     };
     auto unit_ntt = [&](int i) -> int {
         if (i >= nu) return 0;
@@ -176,8 +156,8 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES / 4) void mlp384_kernel(MlpA
         for (int i = 0; i < AREG; ++i) {
             const int ch = (int)threadIdx.x + i * MLP_THREADS, row = ch / 24, c16 = ch - row * 24;
             if (ch < ntt * 16 * 24) {
-                const long long grow = min(tile0 * 16 + row, MM - 1);
-                areg[i] = *reinterpret_cast<const v4i *>(X + grow * MLP_C + c16 * 16);
+                const long long grow = min(tile0 * 16 + row, p.M - 1);
+                areg[i] = *reinterpret_cast<const v4i *>(p.x + grow * MLP_C + c16 * 16);
             }
         }
     };
@@ -378,8 +358,8 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES / 4) void mlp384_kernel(MlpA
 #pragma unroll
                 for (int tt = 0; tt < NTT; ++tt) {
                     acc[j][tt] = b4;
-                    const long long tok = min(tok0 + tt * 16 + tl, MM - 1);
-                    rs[j][tt] = *reinterpret_cast<const v2i *>(RES + tok * MLP_C + ch0);
+                    const long long tok = min(tok0 + tt * 16 + tl, p.M - 1);
+                    rs[j][tt] = *reinterpret_cast<const v2i *>(p.residual + tok * MLP_C + ch0);
                 }
             }
 #pragma unroll
@@ -415,8 +395,8 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES / 4) void mlp384_kernel(MlpA
                         o[e] = min(max(rq_fast(r, p.cr) + rq_fast(t, p.cm), -32768), 32767);
                     }
                     const long long tok = tok0 + tt * 16 + tl;
-                    if (tok < MM && tt < ntt)          // a short unit's surplus tiles belong to the next unit
-                        *reinterpret_cast<v2i *>(OUT + tok * MLP_C + ch0) =
+                    if (tok < p.M && tt < ntt)         // a short unit's surplus tiles belong to the next unit
+                        *reinterpret_cast<v2i *>(p.out + tok * MLP_C + ch0) =
                             v2i{(int)__builtin_amdgcn_perm((unsigned)o[1], (unsigned)o[0], 0x05040100u),
                                 (int)__builtin_amdgcn_perm((unsigned)o[3], (unsigned)o[2], 0x05040100u)};
                 }

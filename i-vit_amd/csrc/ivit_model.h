@@ -15,7 +15,6 @@ struct ivit_vit_s {
     int8_t *gelu_tab;                 // [depth][65536]
     std::vector<ivit_linear_plan> plans;   // per block: qkv, proj, fc1, fc2 (frozen QuantLinear plans, ivit_linear_plan_create)
     std::vector<ivit_mlp_plan> mlp_plans;  // per block: fused Mlp plan (D = 384), or null -> fc1 / ShiftGELU / fc2 launches
-    hipEvent_t mlp_done = nullptr;         // sliced mode: the joined Mlp launch of a block has been issued (slices wait on it)
     int max_slices;
     std::vector<ivit_handle> slice_h; // one handle per internal stream
     std::vector<hipStream_t> streams;
@@ -29,9 +28,6 @@ struct ivit_graph_s {
     hipGraphExec_t exec;
 };
 
-#ifndef IVIT_OPT_JOIN_MLP
-#define IVIT_OPT_JOIN_MLP 1             // sliced ViT forward: one fused-Mlp launch per block over all slices
-#endif
 namespace {
 
 inline size_t al256(size_t n) { return (n + 255) & ~(size_t)255; }
@@ -127,82 +123,6 @@ int run_slice(const ivit_vit_s *m, ivit_handle h, const int8_t *images, int B, i
     return IVIT_OK;
 }
 
-// Sliced forward with the fused Mlp JOINED: every slice runs patch embedding and, per block, LayerNorm / qkv / attention /
-// proj / LayerNorm on its own stream; the block's Mlp is ONE launch over all slices on the caller's stream (the kernel's
-// unit granularity is then that of the whole batch: at 128 images a slice is 98 tokens per CU = two half-empty units per
-// workgroup, the joined 256 are three full ones), after which the slices go on.  Used when every block has a fused Mlp plan.
-int run_joint(const ivit_vit_s *m, const int8_t *images, int batch, int nslices, char *ws, size_t stride, int32_t *logits) {
-    const ivit_vit_config &c = m->cfg;
-    const ivit_vit_params &P = m->prm;
-    const int T = m->T, D = c.embed_dim, H = c.num_heads, dh = D / H, ld = m->ld;
-    const size_t img_bytes = (size_t)c.in_chans * c.img_size * c.img_size;
-    const SliceLayout L = slice_layout(m, max_slice(batch, nslices));
-    ivit_handle h0 = m->h;
-    struct Sl { ivit_handle h; hipStream_t st; int B, b0; char *ws; int16_t *x, *y; };
-    Sl sl[16];
-    for (int s = 0; s < nslices; ++s) {
-        const int b0 = slice_begin(batch, nslices, s), b1 = slice_begin(batch, nslices, s + 1);
-        char *w = ws + stride * (size_t)s;
-        sl[s] = Sl{m->slice_h[s], m->streams[s], b1 - b0, b0, w, (int16_t *)(w + L.xa), (int16_t *)(w + L.xb)};
-    }
-    int rc;
-#define RUNS(hh, call) do { rc = (call); if (rc != IVIT_OK) { snprintf(h0->err, sizeof(h0->err), "%s", (hh)->err); return rc; } } while (0)
-#define HIPOK(call) do { if ((call) != hipSuccess) { snprintf(h0->err, sizeof(h0->err), "ivit_vit_forward: stream / event call failed"); return IVIT_ERR_HIP; } } while (0)
-    HIPOK(hipEventRecord(m->fork, h0->stream));
-    for (int s = 0; s < nslices; ++s) {
-        Sl &S = sl[s];
-        ivit_handle h = S.h;
-        HIPOK(hipStreamWaitEvent(S.st, m->fork, 0));
-        int8_t *patches = (int8_t *)(S.ws + L.patches);
-        int16_t *patch16 = (int16_t *)(S.ws + L.patch16);
-        RUNS(h, ivit_im2col_patch(h, images + (size_t)S.b0 * img_bytes, S.B, c.in_chans, c.img_size, c.img_size, c.patch_size, patches));
-        RUNS(h, ivit_linear_i8_requant(h, patches, P.pe_w, P.pe_b, P.pe_dy, 16, patch16, S.B * m->num_patches, D, m->Kp));
-        RUNS(h, ivit_embed_finish(h, patch16, P.z_cls, P.pos, P.dy_x, P.dy_pos, S.x, S.B, T, D));
-    }
-    for (int i = 0; i < c.depth; ++i) {
-        const ivit_vit_block &b = m->blocks[i];
-        const int8_t *xs[16]; const int16_t *rs[16]; int16_t *os[16]; int64_t Ms[16];
-        for (int s = 0; s < nslices; ++s) {
-            Sl &S = sl[s];
-            ivit_handle h = S.h;
-            const int M = S.B * T;
-            int8_t *a8 = (int8_t *)(S.ws + L.a8), *q = (int8_t *)(S.ws + L.q), *k = (int8_t *)(S.ws + L.k), *vt = (int8_t *)(S.ws + L.vt),
-                   *ctx8 = (int8_t *)(S.ws + L.ctx8);
-            RUNS(h, ivit_layernorm_requant(h, S.x, M, D, D, b.s_ln1, b.n1_bias_int, b.n1_sc, b.n1_dy, a8));
-            RUNS(h, ivit_linear_i8_qkv_planned(h, m->plans[4 * i], a8, q, k, vt, S.B, T, H, dh, ld));
-            if (b.exp_aq)
-                RUNS(h, ivit_attention_fused_lut(h, q, k, vt, b.dy_qk, b.s_softmax, b.exp_aq, b.exp_t, b.exp_cls, b.exp_nc,
-                                                 b.exp_tcount, b.exp_dmin, b.dy_pv, ctx8, S.B, H, T, dh, ld));
-            else
-                RUNS(h, ivit_attention_fused(h, q, k, vt, b.dy_qk, b.s_softmax, b.dy_pv, ctx8, S.B, H, T, dh, ld));
-            RUNS(h, ivit_linear_i8_requant_residual_planned(h, m->plans[4 * i + 1], ctx8, b.res1_main, b.res1_res, S.x, S.y, M));
-            { int16_t *t = S.x; S.x = S.y; S.y = t; }
-            RUNS(h, ivit_layernorm_requant(h, S.x, M, D, D, b.s_ln2, b.n2_bias_int, b.n2_sc, b.n2_dy, a8));
-            HIPOK(hipEventRecord(m->done[s], S.st));
-            xs[s] = a8; rs[s] = S.x; os[s] = S.y; Ms[s] = M;
-        }
-        for (int s = 0; s < nslices; ++s) HIPOK(hipStreamWaitEvent(h0->stream, m->done[s], 0));
-        RUNS(h0, ivit_mlp_fused_segments(h0, m->mlp_plans[i], nslices, xs, m->gelu_tab + (size_t)i * 65536, b.res2_main, b.res2_res, rs, os, Ms));
-        HIPOK(hipEventRecord(m->mlp_done, h0->stream));
-        for (int s = 0; s < nslices; ++s) {
-            HIPOK(hipStreamWaitEvent(sl[s].st, m->mlp_done, 0));
-            int16_t *t = sl[s].x; sl[s].x = sl[s].y; sl[s].y = t;
-        }
-    }
-    for (int s = 0; s < nslices; ++s) {
-        Sl &S = sl[s];
-        ivit_handle h = S.h;
-        int8_t *cls8 = (int8_t *)(S.ws + L.cls8);
-        RUNS(h, ivit_layernorm_requant(h, S.x, S.B, D, (int64_t)T * D, P.s_ln, P.n_bias_int, P.n_sc, P.n_dy, cls8));
-        RUNS(h, ivit_linear_i8(h, cls8, P.head_w, P.head_b, logits + (size_t)S.b0 * c.num_classes, S.B, c.num_classes, D));
-        HIPOK(hipEventRecord(m->done[s], S.st));
-    }
-    for (int s = 0; s < nslices; ++s) HIPOK(hipStreamWaitEvent(h0->stream, m->done[s], 0));
-#undef RUNS
-#undef HIPOK
-    return IVIT_OK;
-}
-
 }  // namespace
 
 extern "C" {
@@ -258,8 +178,7 @@ int ivit_vit_create(ivit_handle h, const ivit_vit_config *cfg, const ivit_vit_pa
         m->mlp_plans.push_back(mp);
     }
     if (max_slices > 1) {
-        bool ok = hipEventCreateWithFlags(&m->fork, hipEventDisableTiming) == hipSuccess &&
-                  hipEventCreateWithFlags(&m->mlp_done, hipEventDisableTiming) == hipSuccess;
+        bool ok = hipEventCreateWithFlags(&m->fork, hipEventDisableTiming) == hipSuccess;
         for (int i = 0; ok && i < max_slices; ++i) {
             // each resource is owned by `m` as soon as it exists, so the destroy on the error path releases it
             hipStream_t st = nullptr;
@@ -288,7 +207,6 @@ int ivit_vit_destroy(ivit_vit m) {
     for (auto ev : m->done) (void)hipEventDestroy(ev);
     for (auto st : m->streams) (void)hipStreamDestroy(st);
     if (m->fork) (void)hipEventDestroy(m->fork);
-    if (m->mlp_done) (void)hipEventDestroy(m->mlp_done);
     if (m->gelu_tab) (void)hipFree(m->gelu_tab);
     for (auto mp : m->mlp_plans) if (mp) (void)ivit_mlp_plan_destroy(mp);
     for (auto pl : m->plans) (void)ivit_linear_plan_destroy(pl);
@@ -335,14 +253,6 @@ int ivit_vit_forward(ivit_vit m, const int8_t *images, int batch, int nslices, v
     const size_t img_bytes = (size_t)m->cfg.in_chans * m->cfg.img_size * m->cfg.img_size;
     const size_t stride = slice_layout(m, max_slice(batch, nslices)).total;
     if (nslices == 1) return run_slice(m, h, images, batch, batch, (char *)workspace, logits);
-    if (IVIT_OPT_JOIN_MLP && m->fused_attention && nslices <= 16) {
-        bool all = true;
-        for (int i = 0; i < m->cfg.depth; ++i) {
-            const ivit_vit_block &b = m->blocks[i];
-            all = all && m->mlp_plans[i] && fabs(b.res2_main.m * b.res2_main.r) < RQ_FAST_CLIM && fabs(b.res2_res.m * b.res2_res.r) < RQ_FAST_CLIM;
-        }
-        if (all) return run_joint(m, images, batch, nslices, (char *)workspace, stride, logits);
-    }
     if (hipEventRecord(m->fork, h->stream) != hipSuccess) return IVIT_ERR_HIP;
     for (int i = 0; i < nslices; ++i) {
         const int b0 = slice_begin(batch, nslices, i), b1 = slice_begin(batch, nslices, i + 1);
