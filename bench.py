@@ -272,6 +272,9 @@ def main():
         ref_all = eng.forward(imgs, nslices=1).clone()
         ok_all = all(bool(torch.equal(step(), ref_all)) for _ in range(5))
         del ref_all
+        if not ok_all:
+            # a wrong image is not a benchmark result: no JSON line, non-zero exit
+            raise SystemExit("bench.py: the sliced / graph forward differs from the unsliced forward in at least one image; nothing timed")
     for _ in range(args.warmup):
         step()
     rep_dt = []
@@ -295,6 +298,8 @@ def main():
     ok = None
     if rank == 0 and batch >= gb:
         ok = bool(np.array_equal(step()[:gb].cpu().numpy(), g["logits_int"]))
+        if not ok:
+            raise SystemExit("bench.py: logits of the golden prefix differ from the reference's; nothing reported")
 
     # per-operator HIP-event timing (separate instrumented steps, one stream, one C-ABI call per operator)
     per = {}

@@ -577,6 +577,16 @@ int ivit_mlp_plan_create(ivit_handle h, ivit_linear_plan fc1, ivit_linear_plan f
     p->fc1 = fc1; p->fc2 = fc2; p->w1f = (v4i *)dev; p->w2f = (v4i *)(dev + wbytes);
     p->fma = fc1->single_fma_ok && fc2->single_fma_ok;
     p->device = h->device;
+    {   // the dynamic-LDS attribute of the kernel this plan will launch: once, here
+        const void *fn = p->fma ? (const void *)mlp384_kernel<true> : (const void *)mlp384_kernel<false>;
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_SMEM);
+        if (e != hipSuccess) {
+            snprintf(h->err, sizeof(h->err), "%s: attr: %s", __func__, hipGetErrorString(e));
+            (void)hipFree(dev);
+            delete p;
+            return IVIT_ERR_HIP;
+        }
+    }
     *out = p;
     return IVIT_OK;
 }
@@ -602,9 +612,7 @@ int ivit_mlp_fused_planned(ivit_handle h, ivit_mlp_plan p, const int8_t *x, cons
         snprintf(h->err, sizeof(h->err), "%s: residual multipliers out of the fast range", __func__);
         return IVIT_ERR_UNSUPPORTED;
     }
-    const void *fn = p->fma ? (const void *)mlp384_kernel<true> : (const void *)mlp384_kernel<false>;
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_SMEM);
-    if (e != hipSuccess) { snprintf(h->err, sizeof(h->err), "%s: attr: %s", __func__, hipGetErrorString(e)); return IVIT_ERR_HIP; }
+    REQUIRE(h, h->device == p->device, "plan and handle live on different devices");
     // one workgroup per CU.  64-token units round-robin unless cutting contiguous tile ranges into units of <= 5 tiles
     // saves a whole round (a unit costs a pass over both weight matrices whatever its size)
     const long long ntiles = (M + 15) / 16, nunits = (ntiles + MLP_TT - 2) / (MLP_TT - 1);
@@ -838,13 +846,15 @@ int ivit_layernorm_requant(ivit_handle h, const int16_t *x, int64_t rows, int C,
         } while (0)
         switch (C) {
             // lanes per row = 4 S (measured on DeiT-S b256: S = 1 23.2 us, S = 2 20.1, S = 4 20.2 — shorter per-wave instruction
-            // chains and more waves per SIMD beat the cheaper quad-only reduction).  S = 1 is NOT dispatched: under
-            // co-residency with GEMM workgroups layernorm_reg_kernel<192, 1> produced sporadic one-LSB differences in a few
-            // adjacent rows (tools/op_stress.py; S = 2 on the same shape: none in 960 launches); the mechanism is not established
-            // (see ivit_layernorm.h)
+            // chains and more waves per SIMD beat the cheaper quad-only reduction).  S = 1 exists in probe builds only
+            // (ivit_layernorm.h has its history)
             case 96: LNR_LAUNCH(96, 2);        // Swin-T/S stage 0 (token-order sums use their own kernel)
             case 128: LNR_LAUNCH(128, 2);      // Swin-B stage 0
+#if IVIT_PROBE_LN192_S1
+            case 192: LNR_LAUNCH(192, 1);      // probe builds only (tools/ln_s1_probe.sh)
+#else
             case 192: LNR_LAUNCH(192, 2);      // DeiT-T, Swin stage 1
+#endif
             case 256: LNR_LAUNCH(256, 2);
             case 384: LNR_LAUNCH(384, 2);      // DeiT-S, Swin stage 2, PatchMerging
             case 512: LNR_LAUNCH(512, 4);
@@ -926,6 +936,8 @@ int ivit_layernorm_tokenorder_requant(ivit_handle h, const int16_t *x, int64_t r
     if (C == 96 || C == 128) {          // Swin-T/S and Swin-B stage 0
         const size_t lds8 = ((size_t)LNT8_ROWS * (C + 1) + C + 2 * LNT8_ROWS) * sizeof(float);
         const unsigned g8 = (unsigned)((rows + LNT8_ROWS - 1) / LNT8_ROWS);
+        REQUIRE(h, (((uintptr_t)x | (uintptr_t)out8 | (uintptr_t)bias_int | (uintptr_t)sc) & 15) == 0,
+                "C = 96 / 128: x, out, bias_int, sc must be 16-byte aligned (vector loads)");
         const void *fn = C == 96 ? (const void *)layernorm_tokenorder8_kernel<1, 96, int16_t> : (const void *)layernorm_tokenorder8_kernel<1, 128, int16_t>;
         int st = set_dyn_lds(h, fn, lds8);
         if (st) return st;
@@ -952,6 +964,8 @@ int ivit_patch_norm_tokenorder(ivit_handle h, const int8_t *x8, int64_t rows, in
     if (C == 96 || C == 128) {
         const size_t lds8 = ((size_t)LNT8_ROWS * (C + 1) + C + 2 * LNT8_ROWS) * sizeof(float);
         const unsigned g8 = (unsigned)((rows + LNT8_ROWS - 1) / LNT8_ROWS);
+        REQUIRE(h, (((uintptr_t)x8 | (uintptr_t)out16 | (uintptr_t)bias_int | (uintptr_t)sc) & 15) == 0,
+                "C = 96 / 128: x, out, bias_int, sc must be 16-byte aligned (vector loads)");
         const void *fn = C == 96 ? (const void *)layernorm_tokenorder8_kernel<2, 96, int8_t> : (const void *)layernorm_tokenorder8_kernel<2, 128, int8_t>;
         int st = set_dyn_lds(h, fn, lds8);
         if (st) return st;

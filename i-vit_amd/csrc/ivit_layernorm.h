@@ -43,16 +43,26 @@ __device__ __forceinline__ float ln_dpp(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
 
-// S = 1 (4 lanes per row, quad_perm broadcasts) is kept for tools/ubench/ln_probe.hip only and MUST NOT be dispatched: it
-// returned one-LSB differences in a few adjacent rows in 1-3 % of the launches that shared CUs with GEMM workgroups
-// (tools/op_stress.py, profiles/README.md round 3).  The mechanism is not established (its ISA interleaves 184 v_pk_*_f32
-// with v_mov_b32_dpp, but that sequence alone does not reproduce it: tools/ubench/dpp_pk_hazard.hip); the S = 2 / S = 4
-// forms are clean under the same stress (960 launches of the same shape, and the whole-model stress runs).
+// S = 1 (4 lanes per row, quad_perm broadcasts) is NOT dispatched (S = 2 is the faster form) and does not compile outside the
+// probe build (-DIVIT_PROBE_LN192_S1=1, tools/ln_s1_probe.sh).  History: it returned one-LSB differences in a few adjacent rows
+// in 1-4 % of the launches that shared CUs with QuantLinear GEMM workgroups.  Round 4 narrowed that to the packed-fp32
+// instructions hipcc used in its sums (v_pk_add/mul/fma_f32; the S = 2 ISA has none): built without packed fp32 it is clean in
+// 20 000 stress launches, with s_nop 7 around each reduction group too; with ds_bpermute instead of DPP, or with the channel
+// constants read from global memory instead of LDS, it still fails.  The library is now built with -packed-fp32-ops off
+// (i-vit_amd/_lib.py), which also covers the S = 4 forms and the token-order kernels whose ISA had packed fp32.
 // 32 rows per block whatever the split: the per-block staging of the channel constants (an fp64 division each) stays ~8 %
 #define LNR_THREADS(S) (128 * (S))
 // timing probes only (tools/ubench/ln_probe.hip): 1 = no output-pass arithmetic, 2 = no second sum, 4 = no Newton loop
 #ifndef LNR_ABLATE
 #define LNR_ABLATE 0
+#endif
+// probes of the S = 1 form only (tools/ln_s1_probe.sh): 1 = s_nop 7 around every DPP group, 2 = ds_bpermute instead of DPP,
+// 3 = per-channel constants straight from global memory instead of the LDS copy
+#ifndef LNR_S1_VARIANT
+#define LNR_S1_VARIANT 0
+#endif
+#ifndef IVIT_PROBE_LN192_S1
+#define IVIT_PROBE_LN192_S1 0
 #endif
 // register budget by values per lane (CC / 4S): <= 24 -> 8 waves per SIMD, <= 48 -> 5, <= 64 -> 4, more -> 3 (no scratch in any
 // instantiation the dispatcher uses)
@@ -65,6 +75,9 @@ __global__ __launch_bounds__(LNR_THREADS(S), LNR_MIN_WAVES(CC, S)) void layernor
                                                                      const float *__restrict__ sc,
                                                                      const ivit_dyadic *__restrict__ dy,
                                                                      int8_t *__restrict__ out) {
+#if !IVIT_PROBE_LN192_S1
+    static_assert(S != 1, "the 4-lanes-per-row form is a probe (see the note above)");
+#endif
     constexpr int LPR = 4 * S, EPC = 8 / S, NSTEP = CC / 32, RPW = 64 / LPR, RPB = (LNR_THREADS(S) / 64) * RPW;
     static_assert(CC % 32 == 0 && NSTEP < 256, "whole 32-element steps, at most one cascade level above the first");
     __shared__ __attribute__((aligned(16))) double cC[CC];
@@ -125,11 +138,28 @@ __global__ __launch_bounds__(LNR_THREADS(S), LNR_MIN_WAVES(CC, S)) void layernor
         for (int e = 0; e < EPC; ++e) {
             const float a = NSTEP >= 16 ? a0[e] + a1[e] : a0[e];
             if constexpr (S == 1) {
-                float t = ln_quad_bcast<0>(a);
-                t += ln_quad_bcast<1>(a);
-                t += ln_quad_bcast<2>(a);
-                t += ln_quad_bcast<3>(a);
+#if LNR_S1_VARIANT == 2
+                // probe: the same four-lane exchange through the LDS crossbar (ds_bpermute) instead of DPP
+                const int l0 = (int)(threadIdx.x & 63) & ~3;
+                float t = __shfl(a, l0);
+                t += __shfl(a, l0 + 1);
+                t += __shfl(a, l0 + 2);
+                t += __shfl(a, l0 + 3);
                 p[e] = t;
+#else
+                float aa = a;
+#if LNR_S1_VARIANT == 1
+                asm volatile("s_nop 7" : "+v"(aa));        // probe: wait states between the producer of `a` and its DPP readers
+#endif
+                float t = ln_quad_bcast<0>(aa);
+                t += ln_quad_bcast<1>(aa);
+                t += ln_quad_bcast<2>(aa);
+                t += ln_quad_bcast<3>(aa);
+#if LNR_S1_VARIANT == 1
+                asm volatile("s_nop 7" : "+v"(t));
+#endif
+                p[e] = t;
+#endif
             } else {
                 float t = a + ln_dpp<0x100 + S>(a);
                 t += ln_dpp<0x100 + 2 * S>(a);
@@ -200,8 +230,13 @@ __global__ __launch_bounds__(LNR_THREADS(S), LNR_MIN_WAVES(CC, S)) void layernor
 #pragma unroll
         for (int e4 = 0; e4 < EPC; e4 += (EPC >= 4 ? 4 : 2)) {
             if constexpr (EPC >= 4) {
+#if LNR_S1_VARIANT == 3
+                v4f b4 = *reinterpret_cast<const v4f *>(bias_int + cb + e4), s4 = *reinterpret_cast<const v4f *>(sc + cb + e4), y4;
+                for (int e = 0; e < 4; ++e) y4[e] = rcp_rn(s4[e]);
+#else
                 const v4f b4 = *reinterpret_cast<const v4f *>(cB + cb + e4), s4 = *reinterpret_cast<const v4f *>(cSc + cb + e4),
                           y4 = *reinterpret_cast<const v4f *>(cY + cb + e4);
+#endif
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { bi[e4 + e] = b4[e]; scv[e4 + e] = s4[e]; yv[e4 + e] = y4[e]; }
             } else {
@@ -211,8 +246,12 @@ __global__ __launch_bounds__(LNR_THREADS(S), LNR_MIN_WAVES(CC, S)) void layernor
 #pragma unroll
         for (int e = 0; e < EPC; e += 2) {
             typedef double v2d __attribute__((ext_vector_type(2)));
+#if LNR_S1_VARIANT == 3
+            cv[e] = dy[cb + e].m * dy[cb + e].r; cv[e + 1] = dy[cb + e + 1].m * dy[cb + e + 1].r;
+#else
             const v2d c2 = *reinterpret_cast<const v2d *>(cC + cb + e);
             cv[e] = c2[0]; cv[e + 1] = c2[1];
+#endif
         }
         unsigned pk[2] = {0, 0};
 #pragma unroll

@@ -121,12 +121,23 @@ class ViTEngine:
             self.h.call("ivit_shiftgelu_build_table", self.f32[p + "mlp.s_gelu"], _dy(self.host[p + "mlp.dy_gelu"]),
                         _P(self.gelu_tab[i].data_ptr()))
 
-        # frozen-QuantLinear plans for forward_ops, built HERE (plan creation allocates and synchronises: not something
-        # to do lazily inside a timed / captured forward); use_plans = False issues the unplanned kernels instead
+        # frozen-QuantLinear plans of the per-operator path (forward_ops / plan()): built on first use by build_op_plans()
+        # — plan creation allocates and synchronises, so callers that time or capture forward_ops call it beforehand; the
+        # native runner (forward) holds its own plans, and an engine that only runs forward() no longer keeps a second
+        # copy of the fragment-ordered Mlp weights (14 MB for DeiT-S).  use_plans = False issues the unplanned kernels
         self.use_plans = True
         self.use_fused_mlp = True       # forward_ops: ivit_mlp_fused_planned where a fused plan exists (D = 384)
         self._plans = {}
         self._mlp_plans = {}
+        self._build_native()
+
+    MAX_SLICES = 8
+
+    def build_op_plans(self):
+        """ivit_linear_plan_create / ivit_mlp_plan_create for every block (idempotent)."""
+        if self._plans:
+            return
+        cfg = self.cfg
         D, Hd = cfg.embed_dim, cfg.hidden_dim
         for i in range(cfg.depth):
             p = f"blocks.{i}."
@@ -135,13 +146,10 @@ class ViTEngine:
             mp = _P()
             if self.h.lib.ivit_mlp_plan_create(self.h.h, self._plans[p + "mlp.fc1"].p, self._plans[p + "mlp.fc2"].p, ctypes.byref(mp)) == 0:
                 self._mlp_plans[i] = mp
-        self._build_native()
-
-    MAX_SLICES = 8
 
     def plan(self, prefix):
-        """frozen-QuantLinear plan (ivit_linear_plan_create) of the layer `prefix`, built in __init__; the native runner
-        holds its own."""
+        """frozen-QuantLinear plan (ivit_linear_plan_create) of the layer `prefix`; the native runner holds its own."""
+        self.build_op_plans()
         return self._plans[prefix].p
 
     def _build_native(self):
@@ -277,6 +285,8 @@ class ViTEngine:
         cfg, call, f32, hc = self.cfg, self.h.call, self.f32, self.host
         assert images.dtype == torch.int8 and images.is_contiguous() and images.device == self.device
         self.h.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        if self.use_plans:
+            self.build_op_plans()
         B = images.shape[0]
         T, D, H, dh, Hd = cfg.num_tokens, cfg.embed_dim, cfg.num_heads, cfg.head_dim, cfg.hidden_dim
         M = B * T

@@ -304,7 +304,11 @@ class QuantAct(nn.Module):
             # the reference's own first step, z = rne(fl(X / s_pre)) in fp32 (quant_utils.py:220): it can exceed int32 after
             # I-LayerNorm, so it stays an integer-valued fp32 tensor for the fp64 requant kernel
             quo = x.float() / _scale_t(s_pre, x, cdim)
-            # A plain fp32 tensor is taken as the reference's fake-quant X = Q * s_pre.  An integer-valued tensor that lost
+            # A plain fp32 tensor is taken as the reference's fake-quant X = Q * s_pre.  Integers are passed as an int dtype or
+            # as IntValued (the explicit convention; torch ops inside __torch_function__ keep the marker).  Only the gross
+            # case of a lost marker is caught below — an I-LayerNorm-sized integer tensor; a small integer-valued fp32
+            # tensor without the marker is indistinguishable from fake-quant values on a coarse grid and IS divided by the
+            # scale (documented limit).  An integer-valued tensor that lost
             # its IntValued marker on the way (.numpy() / .data / an op outside __torch_function__) would be divided by the
             # scale a second time: quotients no operator of the path can produce (the I-LayerNorm output, the largest, stays
             # below 2^40) together with all-integer values are that case — refuse instead of returning other numbers
@@ -565,11 +569,17 @@ class IntSoftmax(nn.Module):
 
     def forward(self, x, scaling_factor, mask=None, num_heads=1):
         """mask: optional float [nW, n, n] (0 / -100.0) — the reference adds it to the fp32 logits
-        right before this module (swin_quant.py:151-156); with integer activations it is passed in."""
+        right before this module (swin_quant.py:151-156); with integer activations it is passed in.
+        Fake-quant logits that already carry that mask are recognised by x < -50 where 128 s < 50 — i.e. the detection is
+        tied to the reference's literal -100.0; another mask value has to be passed through `mask`.  (The x.min() test
+        costs one device sync per call on the fake-quant path; the integer path has none.)"""
         s = np.float32(_f32(scaling_factor)[0])
         fake = _is_fake(x)
         if fake:
             if mask is None and 128.0 * float(s) < 50.0 and x.numel() and x.min().item() < -50.0:
+                if x.dim() < 2 or x.shape[-2] != x.shape[-1]:
+                    raise ValueError("IntSoftmax: fake-quant logits below -50 are taken for the reference's -100.0 shift mask "
+                                     "(swin_quant.py:151-156) and must be [..., n, n]; got " + str(tuple(x.shape)))
                 # The reference's Swin block adds its float mask to the fake-quant logits BEFORE this module
                 # (swin_quant.py:151-156: attn + mask, mask in {0, -100.0}), so a caller running the reference's own model
                 # code hands over X = fl(fl(Q*s) - 100) on the masked entries: off the grid of s, but an integer-domain
@@ -579,8 +589,6 @@ class IntSoftmax(nn.Module):
                 mk_full = torch.where(x < -50.0, torch.full_like(x, -100.0), torch.zeros_like(x)).float()
                 x = from_fake((x.float() - mk_full), s, torch.int8, -128, 127, "IntSoftmax (masked logits)")
                 mask, num_heads = mk_full.reshape(-1, x.shape[-1], x.shape[-1]), 1
-                if x.shape[-2] != x.shape[-1]:
-                    raise ValueError("IntSoftmax: masked fake-quant logits must be [..., n, n]")
             else:
                 x = from_fake(x, s, torch.int8, -128, 127, "IntSoftmax")
         n = x.shape[-1]

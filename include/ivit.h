@@ -368,7 +368,9 @@ int ivit_avgpool_requant(ivit_handle h, const int8_t *x, int B, int L, int C, iv
 int ivit_layernorm_tokenorder(ivit_handle h, const int16_t *x, int64_t rows, int C, float scale,
                               const float *bias_int, const float *sc, int tokens_per_image, float *z);
 
-/* the same with the per-channel QuantAct(8) that follows fused in (out8 int8 [rows, C])         */
+/* the same with the per-channel QuantAct(8) that follows fused in (out8 int8 [rows, C]).  For C = 96 / 128 (the
+ * vectorised kernel) x, out8, bias_int and sc must be 16-byte aligned: IVIT_ERR_INVALID otherwise; the same holds for
+ * ivit_patch_norm_tokenorder below.                                                              */
 int ivit_layernorm_tokenorder_requant(ivit_handle h, const int16_t *x, int64_t rows, int C, float scale,
                                       const float *bias_int, const float *sc, const ivit_dyadic *dy,
                                       int tokens_per_image, int8_t *out8);

@@ -24,6 +24,42 @@ def test_library_exports_header_symbols():
     assert lib.ivit_status_string(1) == b"invalid argument"
 
 
+def _device_code_object(so_path):
+    """The gfx950 ELF inside the library's clang offload bundle (.hip_fatbin)."""
+    import struct
+    b = open(so_path, "rb").read()
+    i = b.find(b"__CLANG_OFFLOAD_BUNDLE__")
+    assert i >= 0, "no offload bundle in the library"
+    n = struct.unpack_from("<Q", b, i + 24)[0]
+    off = i + 32
+    for _ in range(n):
+        o, sz, t = struct.unpack_from("<QQQ", b, off)
+        off += 24
+        name = b[off:off + t].decode()
+        off += t
+        if "gfx950" in name:
+            return b[i + o:i + o + sz]
+    raise AssertionError("no gfx950 code object")
+
+
+def test_no_packed_fp32_in_library(tmp_path):
+    """Round 4: the one-LSB LayerNorm differences beside GEMM workgroups went away with the packed-fp32 instructions; the
+    library is built with -packed-fp32-ops off and its ISA must not contain v_pk_{add,mul,fma}_f32 (profiles/README.md)."""
+    import shutil
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        objdump = shutil.which("llvm-objdump")
+    assert objdump, "llvm-objdump not found"
+    so = iv.build()
+    co = tmp_path / "dev.co"
+    co.write_bytes(_device_code_object(so))
+    dis = subprocess.run([objdump, "-d", str(co)], capture_output=True, text=True, check=True).stdout
+    assert dis.count("v_mfma_i32") > 1000, "disassembly looks wrong"
+    packed = re.findall(r"v_pk_(?:add|mul|fma)_f32", dis)
+    assert not packed, f"{len(packed)} packed-fp32 instructions in libivit_hip.so"
+
+
 def test_no_device_is_an_error_not_a_fallback():
     import ctypes
     import torch

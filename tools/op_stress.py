@@ -85,7 +85,11 @@ for (Rr, hd) in ((28, 6), (14, 12), (7, 24)):
     for shift in ((0, 3) if Rr > 7 else (0,)):
         stress(f"ivit_window_attention_fused R={Rr} heads={hd} shift={shift}", (lambda Rr=Rr, Cc=Cc: torch.empty(B, Rr * Rr, Cc, dtype=torch.int8, device="cuda")),
                (lambda h, o, qk=qk, rb=rb, Rr=Rr, hd=hd, shift=shift: h.call("ivit_window_attention_fused", P(qk), dyv(dq), dyv(da), P(rb), 0.06, dyv(dp), P(o), B, Rr, 7, shift, hd, 32)), None)
-for (Cc, Mm) in ((192, B * 28 * 28), (384, B * 14 * 14), (768, B * 7 * 7), (1536, B * 7 * 7)):
+# LN_BIG=1: the S = 4 register LayerNorm forms (packed-fp32 ISA in the default build) at DeiT-B / ViT-L sized inputs
+_ln_shapes = ((192, B * 28 * 28), (384, B * 14 * 14), (768, B * 7 * 7), (1536, B * 7 * 7))
+if os.environ.get("LN_BIG"):
+    _ln_shapes += ((768, 64 * 197), (1024, 32 * 197))
+for (Cc, Mm) in _ln_shapes:
     xx = dev(rng.integers(-20000, 20000, (Mm, Cc)).astype(np.int16))
     bb = dev(rng.normal(0, 3e5, Cc).astype(np.float32)); ss = dev((10 ** rng.uniform(-10.2, -9.8, Cc)).astype(np.float32))
     dd = dev(iv.freeze.dyadic((10 ** rng.uniform(-10.2, -9.8, Cc)).astype(np.float32), np.float32(0.03)))
