@@ -252,8 +252,11 @@ class QuantAct(nn.Module):
         QuantAct sees — fl(x_int * s_pre) (+ fl(id_int * s_id)) — with the reference's momentum rule,
         then its scale (quant_utils.py:51-69).  Range statistics are torch reductions on the device;
         they run in calibration only, never on the frozen inference path."""
+        ref_val = getattr(x, "_calib_fp32", None)      # IntGELU in calibration mode: the reference's own fp32 tensor
         if s_pre is None:
             X = x.float()
+        elif ref_val is not None and identity is None:
+            X = ref_val
         else:
             X = x.float() * torch.as_tensor(_f32(s_pre), device=x.device)
             if identity is not None:
@@ -529,12 +532,15 @@ class IntGELU(nn.Module):
         self.register_buffer("act_scaling_factor", torch.zeros(1))
         if output_bit != 8:
             raise NotImplementedError("ShiftGELU on MI355X: 8-bit sigmoid (the reference default)")
+        # calibration (the QuantActs start in running_stat mode, freeze_model calls fix()): while set, the output carries the
+        # reference's own fp32 value for the range statistics of the QuantAct that follows (see forward)
+        self.calibrating = True
 
     def fix(self):
-        pass
+        self.calibrating = False
 
     def unfix(self):
-        pass
+        self.calibrating = True
 
     def forward(self, x, scaling_factor=None):
         s = np.float32(_f32(scaling_factor)[0])
@@ -547,7 +553,20 @@ class IntGELU(nn.Module):
         handle(x.device).call("ivit_shiftgelu", _ptr(xc), xc.numel() // C, C, float(s), _ptr(out))
         s_out = np.float32(s * np.float32(1.0 / 2 ** (self.output_bit - 1)))
         self.act_scaling_factor = torch.tensor([float(s_out)])
-        return (to_fake(out, self.act_scaling_factor) if fake else out), self.act_scaling_factor
+        res = to_fake(out, self.act_scaling_factor) if fake else out
+        if self.calibrating:
+            # What the reference hands to the next QuantAct is fl(fl(x_int * sigmoid_int) * s_out) with the NON-integer
+            # x_int = fl(fl(Q s) / s) (quant_modules.py:441-445), one ulp away from fl(Q sigmoid_int s_out) on some elements;
+            # a QuantAct in running_stat mode tracks min / max of exactly that tensor (:170-192).  It is elementwise and
+            # deterministic, so calibration reproduces it (torch fp32 on the device: IEEE multiply and divide);
+            # sigmoid_int = out / Q is exact (out = Q sigmoid_int, |out| < 2^15).  Calibration only.
+            with torch.no_grad():
+                qf = xc.float()
+                st = torch.as_tensor(np.float32(s), device=x.device)
+                pre = (qf * st) / st
+                sig = torch.where(qf != 0, out.float() / torch.where(qf != 0, qf, torch.ones_like(qf)), torch.zeros_like(qf))
+                res._calib_fp32 = (pre * sig) * torch.as_tensor(np.float32(s_out), device=x.device)
+        return res, self.act_scaling_factor
 
 
 class IntSoftmax(nn.Module):
