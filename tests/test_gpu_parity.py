@@ -532,6 +532,58 @@ def test_swin_engine_golden_logits(fname):
         assert np.array_equal(eng.forward(dev(imgs2)).cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("M", [80 * 256 - 1, 80 * 256 + 1, 25216])
+def test_mlp_fused_planned_vs_oracle_production_geometry(M):
+    """the dominant kernel against the ORACLE (oracle/ivit_twin.c chains the restated operators:
+    layers_quant.py:144-153 + vit_quant.py:141-142), not against the HIP chain, at the row counts the headline run
+    produces: 25216 (a half-batch slice of DeiT-S b256) and 80 * 256 -+ 1 (one 5-tile unit per workgroup, one row short /
+    one row over: 4- and 5-tile units, clamped rows, the balanced and the round-robin schedule)."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s"])
+    twin = ctypes.CDLL(os.path.join(ROOT, "oracle", "libivit_oracle.so"))
+    hp = lambda a: a.ctypes.data_as(_P)
+    dyv = lambda d: _lib.Dyadic(float(d[0, 0]), float(d[0, 1]))
+    for name in ("linear_plan_create", "mlp_plan_create", "mlp_fused_planned", "shiftgelu_build_table", "mlp_plan_destroy", "linear_plan_destroy"):
+        getattr(twin, "ivit_cpu_" + name).argtypes = _lib.SIGNATURES.get("ivit_" + name, [_P])     # the destroy calls take the plan only
+        getattr(twin, "ivit_cpu_" + name).restype = ctypes.c_int
+    rng = np.random.default_rng(M)
+    C, Hd = 384, 1536
+    x = rng.integers(-128, 128, (M, C), dtype=np.int8)
+    w1 = np.rint(rng.normal(0, 40, (Hd, C)).clip(-127, 127)).astype(np.int8); b1 = rng.integers(-2000, 2000, Hd).astype(np.int32)
+    w2 = np.rint(rng.normal(0, 40, (C, Hd)).clip(-127, 127)).astype(np.int8); b2 = rng.integers(-2000, 2000, C).astype(np.int32)
+    d1 = iv.freeze.dyadic((10 ** rng.uniform(-5.6, -5.3, Hd)).astype(np.float32), np.float32(0.04))
+    d2 = iv.freeze.dyadic((10 ** rng.uniform(-5.9, -5.6, C)).astype(np.float32), np.float32(2e-4))
+    dm, dr = iv.freeze.dyadic(np.float32(2e-4), np.float32(2.5e-4)), iv.freeze.dyadic(np.float32(3e-4), np.float32(2.5e-4))
+    res = rng.integers(-20000, 20000, (M, C)).astype(np.int16)
+    dg = iv.freeze.dyadic(np.float32(0.04 * 2.0 ** -7), np.float32(0.03))
+    tab = np.zeros(65536, np.int8)
+    assert twin.ivit_cpu_shiftgelu_build_table(None, 0.04, dyv(dg), hp(tab)) == 0
+    H = _lib.Handle(0, torch.cuda.current_stream().cuda_stream)
+    tabd = torch.empty(65536, dtype=torch.int8, device="cuda")
+    H.call("ivit_shiftgelu_build_table", 0.04, dyv(dg), _P(tabd.data_ptr()))
+    d = {k: torch.from_numpy(v).cuda() for k, v in dict(x=x, w1=w1, b1=b1, w2=w2, b2=b2, d1=d1, d2=d2, res=res).items()}
+    g1, g2, gm, c1, c2, cm = (_P() for _ in range(6))
+    H.call("ivit_linear_plan_create", _P(d["w1"].data_ptr()), _P(d["b1"].data_ptr()), _P(d["d1"].data_ptr()), Hd, C, ctypes.byref(g1))
+    H.call("ivit_linear_plan_create", _P(d["w2"].data_ptr()), _P(d["b2"].data_ptr()), _P(d["d2"].data_ptr()), C, Hd, ctypes.byref(g2))
+    H.call("ivit_mlp_plan_create", g1, g2, ctypes.byref(gm))
+    assert twin.ivit_cpu_linear_plan_create(None, hp(w1), hp(b1), hp(d1), Hd, C, ctypes.byref(c1)) == 0
+    assert twin.ivit_cpu_linear_plan_create(None, hp(w2), hp(b2), hp(d2), C, Hd, ctypes.byref(c2)) == 0
+    assert twin.ivit_cpu_mlp_plan_create(None, c1, c2, ctypes.byref(cm)) == 0
+    og = torch.full((M, C), 0x5555, dtype=torch.int16, device="cuda")
+    H.call("ivit_mlp_fused_planned", gm, _P(d["x"].data_ptr()), _P(tabd.data_ptr()), dyv(dm), dyv(dr), _P(d["res"].data_ptr()), _P(og.data_ptr()), M)
+    oc = np.zeros((M, C), np.int16)
+    assert twin.ivit_cpu_mlp_fused_planned(None, cm, hp(x), hp(tab), dyv(dm), dyv(dr), hp(res), hp(oc), M) == 0
+    got = og.cpu().numpy()
+    assert np.array_equal(got, oc), int((got != oc).sum())
+    H.lib.ivit_mlp_plan_destroy(gm); twin.ivit_cpu_mlp_plan_destroy(cm)
+    for pl in (g1, g2):
+        H.lib.ivit_linear_plan_destroy(pl)
+    for pl in (c1, c2):
+        twin.ivit_cpu_linear_plan_destroy(pl)
+
+
 # ---------------------------------------------------------------- calibration (SURVEY §8f N1)
 CALIB_BATCH = {"micro_vit_b2.npz": 4, "micro_vit2h_b3.npz": 4, "deit_tiny_b1.npz": 2, "micro_swin_b2.npz": 4}
 # What is pinned per fixture (measured with tools/calib_diag.py): the FIRST QuantAct site, in forward order, whose calibrated

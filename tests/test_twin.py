@@ -104,16 +104,18 @@ def test_twin_rejects_bad_arguments(twin):
 
 
 # ---------------------------------------------------------------- the same calls through both libraries
-def _cases(rng):
-    """-> list of (entry point, args); an argument is a scalar / Dyadic, ("in", array), ("out", array) or None"""
+def _cases(rng, variant=0):
+    """-> list of (entry point, args); an argument is a scalar / Dyadic, ("in", array), ("out", array) or None.
+    variant 1 is a second argument list per entry point: ragged row counts, other channel / token counts, other scales."""
     I, O = (lambda a: ("in", np.ascontiguousarray(a))), (lambda a: ("out", a))
     cs = []
-    M, N, K = 300, 96, 64
+    V = variant
+    M, N, K = ((300, 96, 64), (173, 160, 128))[V]
     x = rng.integers(-128, 128, (M, K), dtype=np.int8)
     w = np.rint(rng.normal(0, 40, (N, K)).clip(-127, 127)).astype(np.int8)
     b = rng.integers(-3000, 3000, N).astype(np.int32)
-    s_pre = (10 ** rng.uniform(-5.5, -4.5, N)).astype(np.float32)
-    d8, d16 = iv.freeze.dyadic(s_pre, np.float32(2e-2)), iv.freeze.dyadic(s_pre, np.float32(1e-4))
+    s_pre = (10 ** rng.uniform(*((-5.5, -4.5), (-5.1, -4.2))[V], N)).astype(np.float32)
+    d8, d16 = iv.freeze.dyadic(s_pre, np.float32((2e-2, 3.1e-2)[V])), iv.freeze.dyadic(s_pre, np.float32((1e-4, 1.7e-4)[V]))
     dm, dr = iv.freeze.dyadic(np.float32(1e-4), np.float32(2e-4)), iv.freeze.dyadic(np.float32(3e-4), np.float32(2e-4))
     res = rng.integers(-20000, 20000, (M, N)).astype(np.int16)
     cs.append(("quantize_input_f32", [I(rng.normal(0, 1, 5000).astype(np.float32)), 0.02, O(np.zeros(5000, np.int8)), 5000]))
@@ -122,7 +124,7 @@ def _cases(rng):
     cs.append(("linear_i8_requant", [I(x), I(w), I(b), I(d16), 16, O(np.zeros((M, N), np.int16)), M, N, K]))
     cs.append(("linear_i8_requant_residual", [I(x), I(w), I(b), I(d16), dyv(dm), dyv(dr), I(res), O(np.zeros((M, N), np.int16)), M, N, K]))
     # attention-shaped entry points: B = 2, H = 2, T = 50, dh = 64
-    B, Hh, T, dh, ld = 2, 2, 50, 64, 64
+    B, Hh, T, dh, ld = ((2, 2, 50, 64, 64), (3, 1, 37, 64, 48))[V]
     D = Hh * dh
     xq = rng.integers(-128, 128, (B * T, D), dtype=np.int8)
     wq = np.rint(rng.normal(0, 30, (3 * D, D)).clip(-127, 127)).astype(np.int8)
@@ -151,29 +153,33 @@ def _cases(rng):
     cs.append(("requant_f32", [I(z32.astype(np.float32) * 4096.0), I(iv.freeze.dyadic(s_pre * np.float32(1e-3), np.float32(2e-2))), N,
                                None, None, 8, O(np.zeros((M, N), np.int8)), M, N]))
     # elementwise operators
-    s8 = rng.integers(-128, 128, (64, 197), dtype=np.int8)
+    R8 = (64, 61)[V]
+    s8 = rng.integers(-128, 128, (R8, 197), dtype=np.int8)
     s8[3] = -128; s8[4] = 127; s8[5, :] = -100; s8[5, 17] = 90                       # flat, saturated and peaky rows
-    cs.append(("shiftmax", [I(s8), 64, 197, 197, 0.07, 16, O(np.zeros((64, 197), np.uint16)), 197]))
-    cs.append(("shiftmax", [I(s8), 64, 197, 197, 0.11, 8, O(np.zeros((64, 197), np.uint16)), 197]))
-    g8 = rng.integers(-128, 128, (40, 384), dtype=np.int8)
-    g8[2] = rng.integers(-128, -60, 384, dtype=np.int8)                               # an all-negative row
-    dg = iv.freeze.dyadic(np.float32(0.03 * 2.0 ** -7), np.float32(0.025))
+    cs.append(("shiftmax", [I(s8), R8, 197, 197, (0.07, 0.093)[V], 16, O(np.zeros((R8, 197), np.uint16)), 197]))
+    cs.append(("shiftmax", [I(s8), R8, 197, 197, (0.11, 0.157)[V], 8, O(np.zeros((R8, 197), np.uint16)), 197]))
+    Rg, Cg, sg = ((40, 384, 0.03), (37, 768, 0.045))[V]
+    g8 = rng.integers(-128, 128, (Rg, Cg), dtype=np.int8)
+    g8[2] = rng.integers(-128, -60, Cg, dtype=np.int8)                                # an all-negative row
+    dg = iv.freeze.dyadic(np.float32(sg * 2.0 ** -7), np.float32((0.025, 0.033)[V]))
     tab = np.zeros(65536, np.int8)
-    cs.append(("shiftgelu", [I(g8), 40, 384, 0.03, O(np.zeros((40, 384), np.int16))]))
-    cs.append(("shiftgelu_requant", [I(g8), 40, 384, 0.03, dyv(dg), O(np.zeros((40, 384), np.int8))]))
-    cs.append(("shiftgelu_build_table", [0.03, dyv(dg), O(tab)]))
-    C = 192
-    xl = rng.integers(-9000, 9000, (48, C)).astype(np.int16)
+    cs.append(("shiftgelu", [I(g8), Rg, Cg, sg, O(np.zeros((Rg, Cg), np.int16))]))
+    cs.append(("shiftgelu_requant", [I(g8), Rg, Cg, sg, dyv(dg), O(np.zeros((Rg, Cg), np.int8))]))
+    cs.append(("shiftgelu_build_table", [sg, dyv(dg), O(tab)]))
+    C = (192, 384)[V]
+    Rl = (48, 50)[V]
+    xl = rng.integers(-9000, 9000, (Rl, C)).astype(np.int16)
     xl[1] = 1234                                                                       # a zero-variance row
     wl, bl = rng.uniform(0.4, 1.6, C).astype(np.float32), rng.normal(0, 0.3, C).astype(np.float32)
     wl[5] = -0.7
     bias_int, sc = iv.freeze.layernorm_constants(wl, bl)
     dl = iv.freeze.dyadic(sc, np.float32(0.03))
-    cs.append(("layernorm", [I(xl), 48, C, 2.5e-4, I(bias_int), I(sc), O(np.zeros((48, C), np.float32))]))
-    cs.append(("layernorm_requant", [I(xl), 48, C, C, 2.5e-4, I(bias_int), I(sc), I(dl), O(np.zeros((48, C), np.int8))]))
+    sl = (2.5e-4, 3.3e-4)[V]
+    cs.append(("layernorm", [I(xl), Rl, C, sl, I(bias_int), I(sc), O(np.zeros((Rl, C), np.float32))]))
+    cs.append(("layernorm_requant", [I(xl), Rl, C, C, sl, I(bias_int), I(sc), I(dl), O(np.zeros((Rl, C), np.int8))]))
     img = rng.integers(-128, 128, (2, 3, 32, 32), dtype=np.int8)
     cs.append(("im2col_patch", [I(img), 2, 3, 32, 32, 8, O(np.zeros((2 * 16, 3 * 64), np.int8))]))
-    Te, De = 17, 64
+    Te, De = ((17, 64), (10, 128))[V]
     cs.append(("embed_finish", [I(rng.integers(-20000, 20000, (2, Te - 1, De)).astype(np.int16)), I(rng.integers(-10 ** 6, 10 ** 6, De).astype(np.int32)),
                                 I(rng.integers(-20000, 20000, (Te, De)).astype(np.int16)), dyv(dm), dyv(dr), O(np.zeros((2, Te, De), np.int16)), 2, Te, De]))
     # ---- round 3: Swin-specific operators
@@ -187,7 +193,7 @@ def _cases(rng):
     cs.append(("requant_i32_bcast", [I(zb), dyv(da), I(zi), 3 * 2401, dyv(db), 8, O(np.zeros(6 * 3 * 2401, np.int8)), 6 * 3 * 2401]))
     cs.append(("avgpool_requant", [I(rng.integers(-128, 128, (3, 49, 96), dtype=np.int8)), 3, 49, 96, dyv(iv.freeze.dyadic(np.float32(0.03), np.float32(0.02))),
                                    O(np.zeros((3, 96), np.int8))]))
-    Ct, Lt = 96, 64                                                                     # token-order sums: 2 images of 64 tokens
+    Ct, Lt = ((96, 64), (128, 49))[V]                                                   # token-order sums: 2 images of Lt tokens
     xt = rng.integers(-9000, 9000, (2 * Lt, Ct)).astype(np.int16)
     wt, bt = rng.uniform(0.4, 1.6, Ct).astype(np.float32), rng.normal(0, 0.3, Ct).astype(np.float32)
     bit, sct = iv.freeze.layernorm_constants(wt, bt)
@@ -201,12 +207,12 @@ def _cases(rng):
     cs.append(("patch_merge_gather", [I(rng.integers(-128, 128, (2, 14, 14, 96), dtype=np.int8)), 8, 2, 14, 96, O(np.zeros((2, 49, 384), np.int16))]))
     cs.append(("widen_i8_i16", [I(rng.integers(-128, 128, 5000, dtype=np.int8)), O(np.zeros(5000, np.int16)), 5000]))
     # windowed attention: 2 images of 14 x 14 tokens (2 x 2 windows), 3 heads, with and without the cyclic shift
-    Bw, Rw, Hw = 2, 14, 3
+    Bw, Rw, Hw = ((2, 14, 3), (1, 21, 2))[V]
     qkvw = rng.integers(-128, 128, (Bw, Rw, Rw, 3 * Hw * 32), dtype=np.int8)
     relb = rng.integers(-60, 60, (Hw, 49, 49)).astype(np.int16)
-    dwq, dwa, dwp = (iv.freeze.dyadic(np.float32(a), np.float32(b)) for a, b in ((3e-4, 0.05), (0.05, 0.06), (4e-4, 0.03)))
+    dwq, dwa, dwp = (iv.freeze.dyadic(np.float32(a), np.float32(b)) for a, b in (((3e-4, 0.05), (0.05, 0.06), (4e-4, 0.03)), ((2.2e-4, 0.043), (0.043, 0.071), (5e-4, 0.026)))[V])
     for sh in (0, 3):
-        cs.append(("window_attention_fused", [I(qkvw), dyv(dwq), dyv(dwa), I(relb), 0.06, dyv(dwp), O(np.zeros((Bw, Rw * Rw, Hw * 32), np.int8)),
+        cs.append(("window_attention_fused", [I(qkvw), dyv(dwq), dyv(dwa), I(relb), (0.06, 0.071)[V], dyv(dwp), O(np.zeros((Bw, Rw * Rw, Hw * 32), np.int8)),
                                               Bw, Rw, 7, sh, Hw, 32]))
     # ---- the uint8 front end (N3): ToTensor -> Normalize -> input QuantAct; antialiased bicubic resize + centre crop
     u8 = rng.integers(0, 256, (2, 37, 53, 3), dtype=np.uint8)
@@ -238,7 +244,8 @@ def _run(fn, handle, args, to_ptr):
 
 
 @pytest.mark.gpu
-def test_every_twinned_entry_point_agrees_with_the_hip_library(twin):
+@pytest.mark.parametrize("variant", [0, 1])
+def test_every_twinned_entry_point_agrees_with_the_hip_library(twin, variant):
     import torch
     H = _lib.Handle(0, torch.cuda.current_stream().cuda_stream)
     keep = []
@@ -253,7 +260,7 @@ def test_every_twinned_entry_point_agrees_with_the_hip_library(twin):
         keep.append(h)
         return hp(h), h
 
-    cases = _cases(np.random.default_rng(77))
+    cases = _cases(np.random.default_rng(77 + variant), variant)
     seen = set()
     for name, args in cases:
         seen.add(name)
@@ -268,14 +275,15 @@ def test_every_twinned_entry_point_agrees_with_the_hip_library(twin):
                 idx = np.arange(65536)
                 valid = (idx & 255) <= (idx >> 8)
                 g, c = g[valid], c[valid]
+            Tv = (50, 37)[variant]
             if name == "linear_i8_qkv" and i == 2:    # pad columns of v^T (t >= T) are not written by either side
-                g, c = g[:, :, :50], c[:, :, :50]
+                g, c = g[:, :, :Tv], c[:, :, :Tv]
             if name == "attn_qk_requant":
-                g, c = g[:, :, :50], c[:, :, :50]
+                g, c = g[:, :, :Tv], c[:, :, :Tv]
             assert np.array_equal(g, c), (name, i, int((g != c).sum()))
     # planned entry points: same plan-handle protocol on both sides
-    rng = np.random.default_rng(5)
-    M, N, K = 700, 384, 384
+    rng = np.random.default_rng(5 + variant)
+    M, N, K = ((700, 384, 384), (1291, 768, 384))[variant]
     x = rng.integers(-128, 128, (M, K), dtype=np.int8)
     w = np.rint(rng.normal(0, 40, (N, K)).clip(-127, 127)).astype(np.int8)
     b = rng.integers(-3000, 3000, N).astype(np.int32)
@@ -295,7 +303,7 @@ def test_every_twinned_entry_point_agrees_with_the_hip_library(twin):
     H.lib.ivit_linear_plan_destroy.argtypes = [_P]
     assert H.lib.ivit_linear_plan_destroy(pg) == 0 and twin.ivit_cpu_linear_plan_destroy(pc) == 0
     # planned fused Mlp (D = 384): linear plans -> Mlp plan -> one call, on both sides
-    Mm, Cm, Hm = 333, 384, 1536
+    Mm, Cm, Hm = (333, 2051)[variant], 384, 1536       # 2051 = 128 full tiles + 3 rows: several units per workgroup shape
     xm = rng.integers(-128, 128, (Mm, Cm), dtype=np.int8)
     w1 = np.rint(rng.normal(0, 40, (Hm, Cm)).clip(-127, 127)).astype(np.int8); b1 = rng.integers(-2000, 2000, Hm).astype(np.int32)
     w2 = np.rint(rng.normal(0, 40, (Cm, Hm)).clip(-127, 127)).astype(np.int8); b2 = rng.integers(-2000, 2000, Cm).astype(np.int32)
