@@ -362,9 +362,46 @@ __global__ __launch_bounds__(256) void linear_plan_kernel(const int8_t *__restri
         const double zmax = 128.0 * (double)l1 + fabs((double)(bias ? bias[n] : 0));
         int b = 0;
         if (!(fabs(c) * zmax < 2147483000.0)) b |= 1;
-        if (!(fabs(dy[n].m) * zmax < 9007199254740992.0)) b |= 2;
+        if (!(fabs(dy[n].m) * zmax < 9007199254740992.0)) b |= 4;      // bound fails: linear_plan_fma_kernel decides
         if (b) atomicOr(bad, b);
     }
+}
+
+// Channels whose |z * m| may exceed 2^53 (the cheap bound above failed, flag 4): is the one-FMA requant
+//   f1(z) = lo32(fma(double(z), c, 1.5 * 2^52)) = RNE(z * c)            (one rounding)
+// still the reference's  f2(z) = RNE(fl64(z * m) * 2^-e)                (two roundings, quant_utils.py:229-231)  on [-zmax, zmax]?
+// Both are non-decreasing step functions of the integer z; they agree on the clamped 16-bit range (and so on the 8-bit one)
+// iff every step of f1 into a value k in (-32768, 32768] is a step of f2 at the same z.  One block per channel, 65536 steps
+// over 256 threads; steps whose |z * m| < 2^53 are exact in both and skipped.  A failing channel sets flag 2.
+__global__ __launch_bounds__(256) void linear_plan_fma_kernel(const int8_t *__restrict__ w, const int32_t *__restrict__ bias,
+                                                              const ivit_dyadic *__restrict__ dy, int N, int K, int *__restrict__ bad) {
+    __shared__ int s_l1, s_fail;
+    const int n = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) { s_l1 = 0; s_fail = 0; }
+    __syncthreads();
+    int l1 = 0;
+    for (int k = tid; k < K; k += 256) l1 += abs((int)w[(long long)n * K + k]);
+    atomicAdd(&s_l1, l1);
+    __syncthreads();
+    const double m = dy[n].m, r = dy[n].r, c = m * r;
+    const double zmax = 128.0 * (double)s_l1 + fabs((double)(bias ? bias[n] : 0));
+    if (fabs(m) * zmax < 9007199254740992.0) return;               // exact products: nothing to prove
+    if (!(c > 0.0) || !(zmax < 2147483000.0)) { if (tid == 0) atomicOr(bad, 2); return; }
+    auto f1 = [&](double z) { return __double2loint(__builtin_fma(z, c, 6755399441055744.0)); };
+    auto f2 = [&](double z) { return (int)__builtin_rint((z * m) * r); };
+    bool fail = false;
+    for (int i = 0; i < 256 && !fail; ++i) {
+        const int k = -32767 + tid + 256 * i;                        // step INTO k
+        double z0 = __builtin_ceil(((double)k - 0.5) / c);
+        for (int it = 0; it < 4 && z0 - 1.0 >= -zmax && f1(z0 - 1.0) >= k; ++it) z0 -= 1.0;
+        for (int it = 0; it < 4 && z0 <= zmax && f1(z0) < k; ++it) z0 += 1.0;
+        if (fabs(z0) * fabs(m) < 9.0e15) continue;                   // |z * m| < 2^53 around this step
+        if (z0 <= zmax && z0 >= -zmax && (f1(z0) < k || f2(z0) < k)) fail = true;
+        if (z0 - 1.0 <= zmax && z0 - 1.0 >= -zmax && (f1(z0 - 1.0) >= k || f2(z0 - 1.0) >= k)) fail = true;
+    }
+    if (fail) atomicOr(&s_fail, 1);
+    __syncthreads();
+    if (tid == 0 && s_fail) atomicOr(bad, 2);
 }
 
 struct ivit_linear_plan_s {
@@ -399,6 +436,14 @@ int ivit_linear_plan_create(ivit_handle h, const int8_t *w, const int32_t *bias,
     }
     ok = ok && hipMemcpyAsync(&host_bad, flag, sizeof(int), hipMemcpyDeviceToHost, h->stream) == hipSuccess;
     ok = ok && hipStreamSynchronize(h->stream) == hipSuccess;      // plan creation is a build-time call
+    if (ok && (host_bad & 4) && !(host_bad & 1)) {                 // the cheap one-FMA bound failed somewhere: exact proof per channel
+        linear_plan_fma_kernel<<<N, 256, 0, h->stream>>>(w, bias, dy_ch, N, K, flag);
+        ok = hipGetLastError() == hipSuccess;
+        ok = ok && hipMemcpyAsync(&host_bad, flag, sizeof(int), hipMemcpyDeviceToHost, h->stream) == hipSuccess;
+        ok = ok && hipStreamSynchronize(h->stream) == hipSuccess;
+    } else if (host_bad & 4) {
+        host_bad |= 2;
+    }
     if (!ok) {
         snprintf(h->err, sizeof(h->err), "ivit_linear_plan_create: HIP error");
         (void)hipFree(dev);

@@ -42,6 +42,9 @@
 #define MLP_STAB (MLP_SA + MLP_KS1 * MLP_KBLK)    // one ShiftGELU table line (256 B) per half-wave
 #define MLP_SMEM (MLP_STAB + 2 * MLP_WAVES * 256)
 #define MLP_MAGIC 6755399441055744.0
+#ifndef MLP_WD
+#define MLP_WD 3                              // weight fragments in flight ahead of the MFMAs that consume them
+#endif
 // timeline instrumentation (tools/ubench/mlp_probe.hip, -DMLP_TRACE=1): every wave of workgroup 0 stamps s_memtime at the
 // phase boundaries of its first units into p.trace[(unit_index * 8 + wave) * 8 + point]
 #ifndef MLP_TRACE
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES / 4) void mlp384_kernel(MlpA
     extern __shared__ __attribute__((aligned(256))) char sm[];
     constexpr int NJ = MLP_NJ;                        // channel tiles per step
     constexpr int CT1 = MLP_HD / 16 / MLP_WAVES;      // channel tiles of fc1 per wave, in chunks of NJ
-    constexpr int NCH = CT1 / NJ, NS1 = NCH * MLP_KS1, WD = 3;   // fc1 chunks, fc1 steps, weight prefetch distance
+    constexpr int NCH = CT1 / NJ, NS1 = NCH * MLP_KS1, WD = MLP_WD;   // fc1 chunks, fc1 steps, weight prefetch distance
     constexpr int AREG = (MLP_TT * 16 * 24 + MLP_THREADS - 1) / MLP_THREADS;
     static_assert(NJ * 16 * MLP_WAVES == MLP_C && CT1 % NJ == 0, "wave count must split 96 / 24 channel tiles evenly");
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
