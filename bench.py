@@ -110,6 +110,25 @@ def pmc_traffic():
         return None
 
 
+def pmc_traffic_per_kernel(batch, T, D, Hd):
+    """The same per kernel of the GEMM class, next to the algorithmic bytes of that launch (DeiT-S shapes): a class
+    average hides one kernel's wasted re-reads behind another's clean stream."""
+    try:
+        per = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["per_kernel"]
+    except Exception:
+        return None
+    M = batch * T
+    alg = {"mlp384_kernel": M * D + 2 * 2 * M * D + 2 * D * Hd,                 # x, identity in, out, both weight matrices
+           "gemm_as_kernel<5": M * D + 3 * M * D + 3 * D * D,                   # qkv: x, q / k / v^T, weights
+           "gemm_glds_kernel<3": M * D + 2 * 2 * M * D + D * D}                 # proj: ctx, identity in, out, weights
+    out = {}
+    for k, v in per.items():
+        a = next((b for pfx, b in alg.items() if k.startswith(pfx)), None)
+        hbm = (v["fetch_MB_x2"] + v["write_MB"]) * 1e6
+        out[k] = {"hbm_bytes": round(hbm), "algorithmic_bytes": a, "ratio": None if not a else round(hbm / a, 3)}
+    return out
+
+
 def _timed_forward(fwd, make_images, target_seconds, chunk=8, max_images=256):
     """images/s of `fwd` on a time-bounded sample: chunks of `chunk` images until ~target_seconds have passed (never more
     than `max_images`, never less than one chunk); the first chunk is a warm-up and is not counted unless it is the only one"""
@@ -364,6 +383,7 @@ def main():
             "peak": INT8_PEAK_TOPS, "unit": "TOP/s",
             "frac": None if achieved is None else round(achieved / INT8_PEAK_TOPS, 4),
             "traffic": pmc_traffic() if args.model == "deit_small" else None,
+            "traffic_per_kernel": pmc_traffic_per_kernel(batch, cfg.num_tokens, cfg.embed_dim, cfg.hidden_dim) if args.model == "deit_small" else None,
             "launches_per_step": g_n, "ms_per_step_in_kernel": round(g_ms, 4),
             "avg_launch_ms": round(g_ms / g_n, 5) if g_n else None,
             "algorithmic_ops_per_step": lin_ops * batch,
