@@ -42,6 +42,9 @@
 #define MLP_STAB (MLP_SA + MLP_KS1 * MLP_KBLK)    // one ShiftGELU table line (256 B) per half-wave
 #define MLP_SMEM (MLP_STAB + 2 * MLP_WAVES * 256)
 #define MLP_MAGIC 6755399441055744.0
+#ifndef MLP_FC2_SYNC
+#define MLP_FC2_SYNC 0                        // raw s_barrier every n k-steps of the fc2 K loop (0: none)
+#endif
 #ifndef MLP_WD
 #define MLP_WD 3                              // weight fragments in flight ahead of the MFMAs that consume them
 #endif
@@ -368,6 +371,9 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES / 4) void mlp384_kernel(MlpA
 #pragma unroll
             for (int s = 0; s < MLP_KS2; ++s) {
                 __builtin_amdgcn_sched_barrier(0);
+                // keep the two waves of a SIMD abreast: the older one wins every MFMA slot, finishes its K loop thousands of
+                // cycles early and leaves the younger one alone at the single-wave 16x16x64 rate (half the pipe)
+                if (MLP_FC2_SYNC && s > 0 && (s % MLP_FC2_SYNC) == 0) __builtin_amdgcn_s_barrier();
                 if (s + WD < MLP_KS2 && !(MLP_ABLATE & 1)) load_w(s + WD, (s + WD) % (WD + 1));
                 if (s + 1 < MLP_KS2 && !(MLP_ABLATE & 2)) load_b(s + 1, (s + 1) & 1);
                 __builtin_amdgcn_sched_barrier(0);

@@ -600,9 +600,13 @@ __global__ __launch_bounds__(MF_THREADS) void swin_mlp_fused_kernel(MlpFusedArgs
     int *sMax = reinterpret_cast<int *>(sm + MF_MAX);
 
     // ---- one-off: weights -> LDS in fragment (chunk-major) layout, constants
+    // W1's rows are placed so that MFMA row 8g + 4h + e of a 32-channel tile is hidden channel 16h + 4g + e: a lane's 16
+    // fc1 outputs (registers 4g + e) are then 16 CONSECUTIVE channels and leave as one ds_write_b128 (round 4; four
+    // ds_write_b32 at a 32-byte token pitch were 8-way bank conflicts, 29 % of the kernel's LDS time by its PMC run)
     for (int i = tid; i < MF_HD * MF_C / 16; i += MF_THREADS) {          // W1 [384][96]: 6 chunks of 16 B per row
         const int n = i / 6, c16 = i - n * 6, kc = c16 >> 1, hh = c16 & 1;
-        *reinterpret_cast<v4i *>(sm + MF_W1 + kc * (MF_HD * 32) + n * 32 + hh * 16) =
+        const int c = n & 31, slot = (n & ~31) + 8 * ((c >> 2) & 3) + 4 * (c >> 4) + (c & 3);
+        *reinterpret_cast<v4i *>(sm + MF_W1 + kc * (MF_HD * 32) + slot * 32 + hh * 16) =
             *reinterpret_cast<const v4i *>(p.w1 + n * MF_C + c16 * 16);
     }
     for (int i = tid; i < MF_C * MF_HD / 16; i += MF_THREADS) {          // W2 [96][384]: 24 chunks per row
@@ -650,7 +654,7 @@ __global__ __launch_bounds__(MF_THREADS) void swin_mlp_fused_kernel(MlpFusedArgs
             v16i_sw acc;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const v4i b4 = *reinterpret_cast<const v4i *>(sB1 + nt * 32 + g * 8 + half * 4);
+                const v4i b4 = *reinterpret_cast<const v4i *>(sB1 + nt * 32 + half * 16 + g * 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[g * 4 + e] = b4[e];
             }
@@ -661,9 +665,10 @@ __global__ __launch_bounds__(MF_THREADS) void swin_mlp_fused_kernel(MlpFusedArgs
                 acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf, xf, acc, 0, 0, 0);
             }
             int mx = -128;
+            v4i hw;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int n0 = nt * 32 + g * 8 + half * 4;
+                const int n0 = nt * 32 + half * 16 + g * 4;              // registers 4g .. 4g + 3: hidden channels n0 .. n0 + 3
                 int o[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -672,10 +677,10 @@ __global__ __launch_bounds__(MF_THREADS) void swin_mlp_fused_kernel(MlpFusedArgs
                 }
                 unsigned w01 = __builtin_amdgcn_perm((unsigned)o[1], (unsigned)o[0], 0x0c0c0400u);
                 unsigned w23 = __builtin_amdgcn_perm((unsigned)o[3], (unsigned)o[2], 0x0c0c0400u);
-                // hidden channel n0..n0+3 of token (mt*32 + l31): fc2 B-fragment layout [k/32][token][32 B]
-                *reinterpret_cast<unsigned *>(sm + MF_H + nt * (MF_BM * 32) + (mt * 32 + l31) * 32 + g * 8 + half * 4) =
-                    __builtin_amdgcn_perm(w23, w01, 0x05040100u);
+                hw[g] = (int)__builtin_amdgcn_perm(w23, w01, 0x05040100u);
             }
+            // hidden channels 16 half .. + 15 of token (mt*32 + l31): fc2 B-fragment layout [k/32][token][32 B]
+            *reinterpret_cast<v4i *>(sm + MF_H + nt * (MF_BM * 32) + (mt * 32 + l31) * 32 + half * 16) = hw;
             atomicMax(&sMax[mt * 32 + l31], mx);
         }
         __syncthreads();
