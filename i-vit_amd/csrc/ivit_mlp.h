@@ -42,6 +42,9 @@
 #define MLP_STAB (MLP_SA + MLP_KS1 * MLP_KBLK)    // one ShiftGELU table line (256 B) per half-wave
 #define MLP_SMEM (MLP_STAB + 2 * MLP_WAVES * 256)
 #define MLP_MAGIC 6755399441055744.0
+#ifndef MLP_PRIO_YOUNG
+#define MLP_PRIO_YOUNG 0
+#endif
 #ifndef MLP_FC2_SYNC
 #define MLP_FC2_SYNC 0                        // raw s_barrier every n k-steps of the fc2 K loop (0: none)
 #endif
@@ -124,6 +127,7 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES / 4) void mlp384_kernel(MlpA
     constexpr int AREG = (MLP_TT * 16 * 24 + MLP_THREADS - 1) / MLP_THREADS;
     static_assert(NJ * 16 * MLP_WAVES == MLP_C && CT1 % NJ == 0, "wave count must split 96 / 24 channel tiles evenly");
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (MLP_PRIO_YOUNG && wave >= MLP_WAVES / 2) __builtin_amdgcn_s_setprio(1);      // probe: static priority for the younger half
     typedef double v2d __attribute__((ext_vector_type(2)));
 
     // ---- this workgroup's units: (first tile, tiles) of unit i
