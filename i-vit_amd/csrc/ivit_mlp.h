@@ -377,7 +377,7 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES / 4) void mlp384_kernel(MlpA
                 __builtin_amdgcn_sched_barrier(0);
                 // keep the two waves of a SIMD abreast: the older one wins every MFMA slot, finishes its K loop thousands of
                 // cycles early and leaves the younger one alone at the single-wave 16x16x64 rate (half the pipe)
-                if (MLP_FC2_SYNC && s > 0 && (s % MLP_FC2_SYNC) == 0) __builtin_amdgcn_s_barrier();
+                if (MLP_FC2_SYNC && s > 0 && (s % (MLP_FC2_SYNC ? MLP_FC2_SYNC : 1)) == 0) __builtin_amdgcn_s_barrier();
                 if (s + WD < MLP_KS2 && !(MLP_ABLATE & 1)) load_w(s + WD, (s + WD) % (WD + 1));
                 if (s + 1 < MLP_KS2 && !(MLP_ABLATE & 2)) load_b(s + 1, (s + 1) & 1);
                 __builtin_amdgcn_sched_barrier(0);
