@@ -12,15 +12,27 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+// KIND 0: MFMA only; 1: MFMA + LDS fragment reads; 2: MFMA + LDS reads + fp64 requant arithmetic; 3: fp64 arithmetic + LDS, no MFMA.
+// 64 KB of dynamic LDS per workgroup: two aggressor workgroups per CU (16 waves), so that victim workgroups co-reside
+template <int KIND>
 __global__ __launch_bounds__(256) void aggressor(int *out, int n) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
     v4i a, b;
     for (int e = 0; e < 4; ++e) { a[e] = threadIdx.x * 2654435761u + e; b[e] = threadIdx.x * 40503u + e * 977; }
+    for (int i = threadIdx.x; i < 4096; i += 256) reinterpret_cast<v4i *>(lds)[i] = a;
+    __syncthreads();
     v16i c[4];
     for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) c[i][r] = 0;
-    for (int it = 0; it < n; ++it)
+    double acc64 = 0.0;
+    for (int it = 0; it < n; ++it) {
 #pragma unroll
-        for (int m = 0; m < 8; ++m) c[m & 3] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c[m & 3], 0, 0, 0);
-    int s = 0;
+        for (int m = 0; m < 8; ++m) {
+            if (KIND == 1 || KIND == 2 || KIND == 3) a = reinterpret_cast<const v4i *>(lds)[(threadIdx.x + 64 * (m + it)) & 4095];
+            if (KIND != 3) c[m & 3] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c[m & 3], 0, 0, 0);
+            if (KIND >= 2) acc64 = __builtin_fma((double)(a[0] + it), 1.0000001, acc64);
+        }
+    }
+    int s = (int)acc64;
     for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) s += c[i][r];
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
@@ -119,42 +131,41 @@ __global__ __launch_bounds__(128) void victim2(const float *in, int *bad, int n,
 }
 
 int main(int argc, char **argv) {
-    const int reps = argc > 1 ? atoi(argv[1]) : 200;
+    const int reps = argc > 1 ? atoi(argv[1]) : 40;
     float *in; int *bad, *sink;
-    hipMalloc(&in, 1024); hipMalloc(&bad, 8); hipMalloc(&sink, 256 * 2048 * 4);
+    hipMalloc(&in, 1024); hipMalloc(&bad, 8); hipMalloc(&sink, 256 * 4096 * 4);
     float h[256];
     for (int i = 0; i < 256; ++i) h[i] = 1.0f + (rand() % 1000) * 1e-3f;
     hipMemcpy(in, h, 1024, hipMemcpyHostToDevice);
     hipStream_t sv, sa[3];
     hipStreamCreate(&sv);
     for (auto &s : sa) hipStreamCreate(&s);
-    for (int with_aggr = 0; with_aggr < 2; ++with_aggr)
-        for (int nops = 0; nops < 2; ++nops) {
-            hipMemset(bad, 0, 8);
-            hipDeviceSynchronize();
-            for (int r = 0; r < reps; ++r) {
-                if (with_aggr) for (auto &s : sa) aggressor<<<1024, 256, 0, s>>>(sink, 400);
-                if (nops) victim<1><<<2048, 128, 0, sv>>>(in, bad, 2000); else victim<0><<<2048, 128, 0, sv>>>(in, bad, 2000);
-            }
-            hipDeviceSynchronize();
-            int hb = 0;
-            hipMemcpy(&hb, bad, 4, hipMemcpyDeviceToHost);
-            printf("aggressor %d, s_nop 7 after the packed add %d: %d mismatching iterations in %d launches\n", with_aggr, nops, hb, reps);
-        }
-    for (int with_aggr = 0; with_aggr < 2; ++with_aggr)
+    hipFuncSetAttribute((const void *)aggressor<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipFuncSetAttribute((const void *)aggressor<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipFuncSetAttribute((const void *)aggressor<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipFuncSetAttribute((const void *)aggressor<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    for (int kind = -1; kind < 4; ++kind)
         for (int mode = 0; mode < 3; ++mode) {
             hipMemset(bad, 0, 8);
             hipDeviceSynchronize();
             for (int r = 0; r < reps; ++r) {
-                if (with_aggr) for (auto &s : sa) aggressor<<<1024, 256, 0, s>>>(sink, 400);
-                if (mode == 0) victim2<0><<<2048, 128, 0, sv>>>(in, bad, 2000, nullptr);
-                else if (mode == 1) victim2<1><<<2048, 128, 0, sv>>>(in, bad, 2000, nullptr);
-                else victim2<2><<<2048, 128, 0, sv>>>(in, bad, 2000, nullptr);
+                // aggressors first and long-lived (512 workgroups x 2 streams = 2 per CU), victims stream in beside them
+                for (int st = 0; st < 2 && kind >= 0; ++st) {
+                    if (kind == 0) aggressor<0><<<512, 256, 65536, sa[st]>>>(sink, 3000);
+                    if (kind == 1) aggressor<1><<<512, 256, 65536, sa[st]>>>(sink, 3000);
+                    if (kind == 2) aggressor<2><<<512, 256, 65536, sa[st]>>>(sink, 3000);
+                    if (kind == 3) aggressor<3><<<512, 256, 65536, sa[st]>>>(sink, 3000);
+                }
+                for (int k = 0; k < 4; ++k) {
+                    if (mode == 0) victim2<0><<<2048, 128, 0, sv>>>(in, bad, 1000, nullptr);
+                    else if (mode == 1) victim2<1><<<2048, 128, 0, sv>>>(in, bad, 1000, nullptr);
+                    else victim2<2><<<2048, 128, 0, sv>>>(in, bad, 1000, nullptr);
+                }
+                hipDeviceSynchronize();
             }
-            hipDeviceSynchronize();
             int hb = 0;
             hipMemcpy(&hb, bad, 4, hipMemcpyDeviceToHost);
-            printf("emitted sequence: aggressor %d, mode %d (0 as emitted, 1 s_nop 7 everywhere, 2 scalar adds): %d mismatching iterations in %d launches\n", with_aggr, mode, hb, reps);
+            printf("aggressor kind %d (-1 none, 0 MFMA, 1 +LDS reads, 2 +fp64, 3 fp64+LDS only), victim mode %d (0 emitted, 1 s_nop 7, 2 scalar adds): %d mismatching iterations in %d x 4 launches\n", kind, mode, hb, reps);
         }
     return 0;
 }
