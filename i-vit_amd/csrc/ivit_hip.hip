@@ -895,7 +895,9 @@ int ivit_layernorm_requant(ivit_handle h, const int16_t *x, int64_t rows, int C,
             // (ivit_layernorm.h has its history)
             case 96: LNR_LAUNCH(96, 2);        // Swin-T/S stage 0 (token-order sums use their own kernel)
             case 128: LNR_LAUNCH(128, 2);      // Swin-B stage 0
-#if IVIT_PROBE_LN192_S1
+#if IVIT_PROBE_LN192_S1 == 2
+            case 192: break;                   // probe: C = 192 on layernorm16_kernel, the round-2 LayerNorm
+#elif IVIT_PROBE_LN192_S1
             case 192: LNR_LAUNCH(192, 1);      // probe builds only (tools/ln_s1_probe.sh)
 #else
             case 192: LNR_LAUNCH(192, 2);      // DeiT-T, Swin stage 1

@@ -89,6 +89,8 @@ for (Rr, hd) in ((28, 6), (14, 12), (7, 24)):
 _ln_shapes = ((192, B * 28 * 28), (384, B * 14 * 14), (768, B * 7 * 7), (1536, B * 7 * 7))
 if os.environ.get("LN_BIG"):
     _ln_shapes += ((768, 64 * 197), (1024, 32 * 197))
+if os.environ.get("LN_ODD"):            # a channel count outside the register kernel's list: layernorm16_kernel, the round-2 LayerNorm
+    _ln_shapes += ((200, B * 28 * 28),)
 for (Cc, Mm) in _ln_shapes:
     xx = dev(rng.integers(-20000, 20000, (Mm, Cc)).astype(np.int16))
     bb = dev(rng.normal(0, 3e5, Cc).astype(np.float32)); ss = dev((10 ** rng.uniform(-10.2, -9.8, Cc)).astype(np.float32))
