@@ -168,6 +168,10 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void attn_fused_kernel(AttnArgs p) 
         const float mx = sXq[qmax + 128 - VB];
         // byte offset of aq[class(vmax)][v' = 0]: ((class * 256 + 128) - VB) * 2
         const int rowbase2 = LUT ? ((int)sCls[qmax + 128 - VB] * 256 + 128 - VB) * 2 : 0;
+        // LDS address of this query row's table line, once per row: the first gather's address is then ONE v_lshl_add_u32 per
+        // score (round 4: left to the compiler it was a shift plus a three-input add on the run-time table base, 1.4 + 1.3 per score)
+        typedef __attribute__((address_space(3))) const char att_lds_c;
+        const unsigned aqrow = (unsigned)(size_t)((att_lds_c *)sAQ) + (unsigned)rowbase2;
 
         // ---- shift-exp; keys >= T contribute exactly 0
         if (LUT) {
@@ -182,15 +186,20 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void attn_fused_kernel(AttnArgs p) 
                     if (j0 + jj < C::NT && j0 + jj < ntile) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            e1[jj][r] = (int)*reinterpret_cast<const unsigned short *>(
-                                reinterpret_cast<const char *>(sAQ) + ((__float_as_int(f[j0 + jj][r]) << 1) + rowbase2));
+                            e1[jj][r] = (int)*reinterpret_cast<__attribute__((address_space(3))) const unsigned short *>(
+                                (size_t)(((unsigned)__float_as_int(f[j0 + jj][r]) << 1) + aqrow));
                     }
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj)
                     if (j0 + jj < C::NT && j0 + jj < ntile) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
+                        {
                             e1[jj][r] += (int)(__builtin_elementwise_sub_sat((unsigned)__float_as_int(f[j0 + jj][r]), qd) << 2);
+                            // opaque: otherwise the sum is re-associated with the (zero) LDS base of the table into a shift plus a
+                            // three-input add instead of one v_lshl_add_u32
+                            asm("" : "+v"(e1[jj][r]));
+                        }
                     }
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj)
@@ -198,7 +207,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void attn_fused_kernel(AttnArgs p) 
                         const int j = j0 + jj;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const float e = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(sT) + e1[jj][r]);
+                            const float e = *reinterpret_cast<__attribute__((address_space(3))) const float *>((att_lds_c *)sT + (unsigned)e1[jj][r]);
                             f[j][r] = (j * 16 + 15 < T || j * 16 + g * 4 + r < T) ? e : 0.f;
                         }
                     }
