@@ -31,6 +31,9 @@ struct AttnArgs {
 };
 
 #define ATT_WAVES 7
+#ifndef ATT_PROBE          // timing probes only (results invalid): 1 first gather lane-linear, 2 second gather lane-linear with the
+#define ATT_PROBE 0        // first one dead, 4 second gather lane-linear with the first one kept alive, 8 no second gather
+#endif
 #define ATT_DH 64
 
 __device__ __forceinline__ int att_kswz(int row, int g) {   // 16-byte chunk position in a K row
@@ -65,7 +68,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void attn_fused_kernel(AttnArgs p) 
     int *sCol = reinterpret_cast<int *>(sO + C::SO_BYTES);
     float *sXq = reinterpret_cast<float *>(sO + C::SO_BYTES + 256);   // fl(fl(Q*s)/s) for Q = -128..127
     float *sT = reinterpret_cast<float *>(dsmem + C::SMEM);           // LUT only: exp table, then aq, then cls
-    unsigned short *sAQ = reinterpret_cast<unsigned short *>(sT + (LUT ? p.t_count : 0));
+    unsigned short *sAQ = reinterpret_cast<unsigned short *>(sT + (LUT ? (p.t_count + 3) & ~3 : 0));   // 16-byte aligned
     unsigned char *sCls = reinterpret_cast<unsigned char *>(sAQ + (LUT ? p.nc * 256 : 0));
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -75,43 +78,72 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void attn_fused_kernel(AttnArgs p) 
     const int8_t *kg = p.k + (long long)bh * T * 64;
     const int8_t *vg = p.vt + (long long)bh * 64 * p.ldv;
 
-    // ---- stage K (rows >= T zero) and V^T (keys >= T zero, permuted) into LDS
-    for (int c = tid; c < C::TK * 4; c += ATT_WAVES * 64) {
-        int row = c >> 2, g = c & 3;
-        v4i v = {0, 0, 0, 0};
-        if (row < T) v = *reinterpret_cast<const v4i *>(kg + row * 64 + g * 16);
-        *reinterpret_cast<v4i *>(sK + row * 64 + att_kswz(row, g) * 16) = v;
+    // ---- stage K (rows >= T zero) and V^T (keys >= T zero, permuted) into LDS, and the tables.
+    // Every global load of the prologue is issued before the first one is waited for (round 4: written as load-store
+    // loops it was ~20 serial memory latencies per workgroup, 9 us of the launch when timed alone)
+    constexpr int NTH = ATT_WAVES * 64;
+    constexpr int KI = (C::TK * 4 + NTH - 1) / NTH, VI = (64 * C::NT + NTH - 1) / NTH;
+    v4i kreg[KI], vreg[VI];
+#pragma unroll
+    for (int i = 0; i < KI; ++i) {
+        const int c = tid + i * NTH, row = c >> 2, g = c & 3;
+        kreg[i] = v4i{0, 0, 0, 0};
+        if (c < C::TK * 4 && row < T) kreg[i] = *reinterpret_cast<const v4i *>(kg + row * 64 + g * 16);
     }
-    for (int c = tid; c < 64 * C::NT; c += ATT_WAVES * 64) {
-        int d = c / C::NT, i = c - d * C::NT;   // i: 16-key chunk index
-        int t0 = i * 16;
-        v4i v = {0, 0, 0, 0};
-        if (t0 < T) {
-            v = *reinterpret_cast<const v4i *>(vg + (long long)d * p.ldv + t0);
-            if (t0 + 16 > T) {
-                int valid = T - t0;
+#pragma unroll
+    for (int i = 0; i < VI; ++i) {
+        const int c = tid + i * NTH, d = c / C::NT, t0 = (c - d * C::NT) * 16;
+        vreg[i] = v4i{0, 0, 0, 0};
+        if (c < 64 * C::NT && t0 < T) vreg[i] = *reinterpret_cast<const v4i *>(vg + (long long)d * p.ldv + t0);
+    }
+    if (LUT && !(ATT_PROBE & 32)) {
+        // table offsets are staged as BYTE offsets into sT (x4: t_count <= 16384 keeps them in 16 bits): a score's
+        // table address is then one v_lshl_add_u32 on top of the saturating distance
+        const int n4 = p.t_count >> 2, a4 = p.nc * 32;          // whole 16-byte chunks (the launcher checks the alignment)
+        for (int i0 = tid; i0 < n4; i0 += 4 * NTH) {
+            v4i t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i0 + u * NTH < n4) t[u] = reinterpret_cast<const v4i *>(p.et)[i0 + u * NTH];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i0 + u * NTH < n4) reinterpret_cast<v4i *>(sT)[i0 + u * NTH] = t[u];
+        }
+        if (tid < (p.t_count & 3)) sT[(n4 << 2) + tid] = p.et[(n4 << 2) + tid];
+        for (int i = tid; i < a4; i += NTH) {
+            v4i t = reinterpret_cast<const v4i *>(p.aq)[i];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) t[u] = (int)(((unsigned)t[u] & 0x3fff3fffu) << 2);
+            *reinterpret_cast<v4i *>(reinterpret_cast<char *>(sAQ) + i * 16) = t;
+        }
+        if (tid < 64) reinterpret_cast<unsigned *>(sCls)[tid] = reinterpret_cast<const unsigned *>(p.cls)[tid];
+    }
+#pragma unroll
+    for (int i = 0; i < KI; ++i) {
+        const int c = tid + i * NTH, row = c >> 2, g = c & 3;
+        if (c < C::TK * 4) *reinterpret_cast<v4i *>(sK + row * 64 + att_kswz(row, g) * 16) = kreg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < VI; ++i) {
+        const int c = tid + i * NTH, d = c / C::NT, ci = c - d * C::NT, t0 = ci * 16;   // ci: 16-key chunk index
+        if (c < 64 * C::NT) {
+            v4i v = vreg[i];
+            if (t0 < T && t0 + 16 > T) {
+                const int valid = T - t0;
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
-                    int nb = valid - w * 4;
-                    unsigned m = nb >= 4 ? 0xffffffffu : (nb <= 0 ? 0u : ((1u << (nb * 8)) - 1u));
+                    const int nb = valid - w * 4;
+                    const unsigned m = nb >= 4 ? 0xffffffffu : (nb <= 0 ? 0u : ((1u << (nb * 8)) - 1u));
                     v[w] &= (int)m;
                 }
             }
-        }
-        int kb = i >> 2, jj = i & 3;
-        char *dst = sV + d * C::VS + kb * 64 + jj * 4;
+            const int kb = ci >> 2, jj = ci & 3;
+            char *dst = sV + d * C::VS + kb * 64 + jj * 4;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) *reinterpret_cast<int *>(dst + g * 16) = v[g];
+            for (int g = 0; g < 4; ++g) *reinterpret_cast<int *>(dst + g * 16) = v[g];
+        }
     }
     if (tid < 256) sXq[tid] = requotient_c((float)(tid - 128), rcp_prepare(p.s_softmax));
-    if (LUT) {
-        for (int i = tid; i < p.t_count; i += ATT_WAVES * 64) sT[i] = p.et[i];
-        // table offsets are staged as BYTE offsets into sT (x4: t_count <= 16384 keeps them in 16 bits): a score's
-        // table address is then one v_lshl_add_u32 on top of the saturating distance
-        for (int i = tid; i < p.nc * 128; i += ATT_WAVES * 64)
-            reinterpret_cast<unsigned *>(sAQ)[i] = (reinterpret_cast<const unsigned *>(p.aq)[i] & 0x3fff3fffu) << 2;
-        if (tid < 64) reinterpret_cast<unsigned *>(sCls)[tid] = reinterpret_cast<const unsigned *>(p.cls)[tid];
-    }
     __syncthreads();
     if (tid < 64) {  // column sums of V (per d) over all keys
         int s = 0;
@@ -132,11 +164,17 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void attn_fused_kernel(AttnArgs p) 
     const int nqt = (T + 15) >> 4;         // query tiles
     const int nvec = T >> 3, size = nvec >> 2;
 
+    if (ATT_PROBE & 16) return;           // prologue only
+    v4i qnext = {0, 0, 0, 0};
+    if (wave < nqt && wave * 16 + qi < T) qnext = *reinterpret_cast<const v4i *>(qg + (wave * 16 + qi) * 64 + g * 16);
     for (int qt = wave; qt < nqt; qt += ATT_WAVES) {
         const int q0 = qt * 16;
         // ---- Q fragment (B operand): query qi, dh bytes [16g, 16g+16)
-        v4i qf = {0, 0, 0, 0};
-        if (q0 + qi < T) qf = *reinterpret_cast<const v4i *>(qg + (q0 + qi) * 64 + g * 16);
+        const v4i qf = qnext;
+        if (qt + ATT_WAVES < nqt) {            // the next tile's fragment travels while this one is worked on
+            qnext = v4i{0, 0, 0, 0};
+            if (q0 + ATT_WAVES * 16 + qi < T) qnext = *reinterpret_cast<const v4i *>(qg + (q0 + ATT_WAVES * 16 + qi) * 64 + g * 16);
+        }
 
         // ---- S^T tiles -> requant -> x~ = fl(fl(Q*s)/s) by table; running integer max
         // LUT form: scores are carried with a bias of VB = 384 (v' = v + 384 in [256, 511]; the bias rides in the requant's
@@ -187,16 +225,15 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void attn_fused_kernel(AttnArgs p) 
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             e1[jj][r] = (int)*reinterpret_cast<__attribute__((address_space(3))) const unsigned short *>(
-                                (size_t)(((unsigned)__float_as_int(f[j0 + jj][r]) << 1) + aqrow));
+                                (size_t)(ATT_PROBE & 1 ? aqrow + ((unsigned)(threadIdx.x & 63) << 1) : (((unsigned)__float_as_int(f[j0 + jj][r]) << 1) + aqrow)));
                     }
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj)
                     if (j0 + jj < C::NT && j0 + jj < ntile) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                        {
+                        for (int r = 0; r < 4; ++r) {
                             e1[jj][r] += (int)(__builtin_elementwise_sub_sat((unsigned)__float_as_int(f[j0 + jj][r]), qd) << 2);
-                            // opaque: otherwise the sum is re-associated with the (zero) LDS base of the table into a shift plus a
+                            // opaque: otherwise the sum is re-associated with the LDS base of the table into a shift plus a
                             // three-input add instead of one v_lshl_add_u32
                             asm("" : "+v"(e1[jj][r]));
                         }
@@ -207,7 +244,9 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void attn_fused_kernel(AttnArgs p) 
                         const int j = j0 + jj;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const float e = *reinterpret_cast<__attribute__((address_space(3))) const float *>((att_lds_c *)sT + (unsigned)e1[jj][r]);
+                            if (ATT_PROBE & 4) asm volatile("" :: "v"(e1[jj][r]));
+                            const float e = ATT_PROBE & 8 ? __int_as_float(e1[jj][r]) : *reinterpret_cast<__attribute__((address_space(3))) const float *>(
+                                (att_lds_c *)(size_t)(unsigned)C::SMEM + (ATT_PROBE & 6 ? ((unsigned)(threadIdx.x & 63) << 2) + (ATT_PROBE & 2 ? (unsigned)e1[jj][r] & 0u : 0u) : (unsigned)e1[jj][r]));
                             f[j][r] = (j * 16 + 15 < T || j * 16 + g * 4 + r < T) ? e : 0.f;
                         }
                     }

@@ -674,7 +674,7 @@ int ivit_mlp_fused_planned(ivit_handle h, ivit_mlp_plan p, const int8_t *x, cons
 
 template <int NB, bool FAST, int TT = 0, bool LUT = false>
 static int launch_attn2(ivit_handle h, const AttnArgs &a, int BH) {
-    const size_t lds = AttCfg<NB>::SMEM + (LUT ? (size_t)a.t_count * 4 + (size_t)a.nc * 512 + 256 : 0);
+    const size_t lds = AttCfg<NB>::SMEM + (LUT ? (size_t)((a.t_count + 3) & ~3) * 4 + (size_t)a.nc * 512 + 256 : 0);
     if (lds > 65536) {
         hipError_t e = hipFuncSetAttribute((const void *)attn_fused_kernel<NB, FAST, TT, LUT>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -712,6 +712,8 @@ static int attention_fused_impl(ivit_handle h, const int8_t *q, const int8_t *k,
     }
     if (aq) REQUIRE(h, et && cls && nc >= 1 && nc <= 64 && t_count >= 1 && t_count <= 16384 && dmin <= 0 && dmin >= -255,
                     "bad Shiftmax tables");
+    if (aq) REQUIRE(h, (((uintptr_t)aq | (uintptr_t)et) & 15) == 0 && ((uintptr_t)cls & 3) == 0,
+                    "Shiftmax tables: exp_aq and exp_t must be 16-byte aligned, exp_cls 4-byte aligned (copied in 16-byte pieces)");
     AttnArgs a;
     a.q = q; a.k = k; a.vt = vt; a.ctx = ctx8; a.T = T; a.H = H; a.ldv = ldv;
     a.s_softmax = s_softmax; a.dy_qk = dy_qk; a.dy_pv = dy_pv;
