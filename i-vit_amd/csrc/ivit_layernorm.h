@@ -19,6 +19,7 @@
 // fma(q0, d, -n) is exact: three VALU operations instead of the eleven of an IEEE division or the six of the hoisted
 // Newton form (ivit_device.h::lean_div).  Pinned against `/` in tests/test_gpu_parity.py::test_markstein_requotient.
 #pragma once
+#include <type_traits>
 #include "ivit_device.h"
 
 // fl(fl(q * d) / d) for a float q with |q| < 2^24 * ulp-safe range, yd = RN(1 / d)
@@ -83,14 +84,21 @@ __global__ __launch_bounds__(LNR_THREADS(S), LNR_MIN_WAVES(CC, S)) void layernor
     __shared__ __attribute__((aligned(16))) double cC[CC];
     __shared__ __attribute__((aligned(16))) float cB[CC], cSc[CC], cY[CC];
     const int tid = threadIdx.x;
+    // The 8-bit requant rne(fl64(z * c)) is taken as the low dword of fl64(z * c) + (1.5 * 2^52 + 128) — the same two roundings
+    // as the reference (quant_utils.py:229-231) in two fp64 operations instead of four, biased to 0..255 so the four bytes of
+    // a dword pack without masks.  That needs |z * c| < 2^31: |y| <= 2^16 and k >= 2^16 / 2^10 after ten halvings at most bound
+    // |o| by 2^40 + |bias|; a block with a channel where that bound fails keeps v_rndne_f64 + the saturating v_cvt_i32_f64.
+    bool wide = false;
     for (int c = tid; c < CC; c += LNR_THREADS(S)) {
-        const float scv = sc[c];
+        const float scv = sc[c], bv = bias_int[c];
+        const double cv = dy[c].m * dy[c].r;
         cSc[c] = scv;
         cY[c] = rcp_rn(scv);
-        cB[c] = bias_int[c];
-        cC[c] = dy[c].m * dy[c].r;
+        cB[c] = bv;
+        cC[c] = cv;
+        wide |= !(fabs(cv) * (1.2e12 + 1.01 * fabs((double)bv)) < 2147483000.0);
     }
-    __syncthreads();
+    const bool fastrq = !__syncthreads_or(wide);
     const int lane = tid & 63, j = lane % LPR, k = j / S, hh = j % S;
     const long long row_raw = (long long)blockIdx.x * RPB + (tid >> 6) * RPW + lane / LPR;
     const bool live = row_raw < rows;
@@ -222,6 +230,7 @@ __global__ __launch_bounds__(LNR_THREADS(S), LNR_MIN_WAVES(CC, S)) void layernor
 
     // ---- pass 3: normalise, requotient by the channel scale, 8-bit requant, store
     int8_t *op = out + row * CC + 8 * k + EPC * hh;
+    auto pass3 = [&](auto fast) {
 #pragma unroll
     for (int i = 0; i < NSTEP; ++i) {
         const int cb = 32 * i + 8 * k + EPC * hh;
@@ -254,13 +263,24 @@ __global__ __launch_bounds__(LNR_THREADS(S), LNR_MIN_WAVES(CC, S)) void layernor
 #endif
         }
         unsigned pk[2] = {0, 0};
+        if constexpr (decltype(fast)::value) {
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-            const float o = floorf(xv[i][e] * Fh) + bi[e];
-            if (LNR_ABLATE & 1) { pk[e >> 2] |= ((unsigned)__float_as_int(o) & 0xffu) << (8 * (e & 3)); continue; }
-            const float zz = rintf(requotient_m(o, scv[e], yv[e]));
-            const int v = rq_c((double)zz, cv[e], -128, 127);
-            pk[e >> 2] |= ((unsigned)v & 0xffu) << (8 * (e & 3));
+            for (int e = 0; e < EPC; ++e) {
+                const float o = floorf(xv[i][e] * Fh) + bi[e];
+                if (LNR_ABLATE & 1) { pk[e >> 2] |= ((unsigned)__float_as_int(o) & 0xffu) << (8 * (e & 3)); continue; }
+                const float zz = rintf(requotient_m(o, scv[e], yv[e]));
+                const int v = __double2loint((double)zz * cv[e] + (6755399441055744.0 + 128.0));
+                pk[e >> 2] |= (unsigned)min(max(v, 0), 255) << (8 * (e & 3));
+            }
+            pk[0] ^= 0x80808080u; pk[1] ^= 0x80808080u;
+        } else {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const float o = floorf(xv[i][e] * Fh) + bi[e];
+                const float zz = rintf(requotient_m(o, scv[e], yv[e]));
+                const int v = rq_c((double)zz, cv[e], -128, 127);
+                pk[e >> 2] |= ((unsigned)v & 0xffu) << (8 * (e & 3));
+            }
         }
         if (live) {
             if constexpr (EPC == 8) *reinterpret_cast<v2i *>(op + 32 * i) = v2i{(int)pk[0], (int)pk[1]};
@@ -268,6 +288,10 @@ __global__ __launch_bounds__(LNR_THREADS(S), LNR_MIN_WAVES(CC, S)) void layernor
             else *reinterpret_cast<unsigned short *>(op + 32 * i) = (unsigned short)pk[0];
         }
     }
+    };
+    // one branch around the whole pass (left inside, both forms are evaluated per element and selected)
+    if (fastrq) pass3(std::true_type{});
+    else pass3(std::false_type{});
 }
 
 // diagnostics: requotient_m against the IEEE sequence fl(fl(q*d)/d), element-wise
