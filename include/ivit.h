@@ -166,7 +166,8 @@ int ivit_attention_fused(ivit_handle h, const int8_t *q, const int8_t *k, const 
 /* The same with Shiftmax's exp_int taken from tables built on the host for the layer's frozen scale
  * (ivit_amd.freeze.shiftmax_tables; exhaustively checked against the arithmetic form when built):
  * exp_int = exp_t[exp_aq[exp_cls[vmax]][v] + max(v - vmax, dmin) - dmin].  exp_aq uint16 [nclass][256],
- * exp_t float [t_count], exp_cls uint8 [256] (device).  Same integers as ivit_attention_fused.        */
+ * exp_t float [t_count], exp_cls uint8 [256] (device; exp_aq and exp_t 16-byte aligned, exp_cls 4-byte aligned — they are
+ * copied into LDS in 16-byte pieces; IVIT_ERR_INVALID otherwise).  Same integers as ivit_attention_fused.        */
 int ivit_attention_fused_lut(ivit_handle h, const int8_t *q, const int8_t *k, const int8_t *vt,
                              ivit_dyadic dy_qk, float s_softmax, const uint16_t *exp_aq, const float *exp_t,
                              const uint8_t *exp_cls, int nclass, int t_count, int dmin, ivit_dyadic dy_pv,

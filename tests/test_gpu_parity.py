@@ -886,6 +886,12 @@ def test_attention_shiftmax_tables_equal_arithmetic(H, scale):
                P(dev(tabs["cls"])), int(tabs["NC"]), int(tabs["t"].size), int(tabs["dmin"]), dyv(dpv), P(o2), B, Hh, T, dh, ld)
         assert np.array_equal(o1.cpu().numpy(), o2.cpu().numpy()), (scale, T)
         assert len(np.unique(o1.cpu().numpy())) > 20
+    # the tables are copied in 16-byte pieces: a misaligned exp_t is refused, not mis-read
+    shifted = dev(np.concatenate([np.zeros(1, np.float32), tabs["t"]]))
+    with pytest.raises(_lib.IvitError, match="16-byte aligned"):
+        H.call("ivit_attention_fused_lut", P(q), P(k), P(vt), dyv(dqk), float(scale), P(dev(tabs["aq"])),
+               ctypes.c_void_p(shifted.data_ptr() + 4), P(dev(tabs["cls"])), int(tabs["NC"]), int(tabs["t"].size),
+               int(tabs["dmin"]), dyv(dpv), P(o2), B, Hh, T, dh, ld)
 
 
 # ---------------------------------------------------------------- persistent pipelined GEMMs (csrc/ivit_gemm3.h)
