@@ -103,6 +103,8 @@ class SwinBlock(ctypes.Structure):
         ("res1_main", Dyadic), ("res1_res", Dyadic),
         ("s_mid", ctypes.c_float), ("n2", LnParams), ("fc1", LinParams), ("s_gelu", ctypes.c_float), ("dy_gelu", Dyadic),
         ("fc2", LinParams), ("res2_main", Dyadic), ("res2_res", Dyadic),
+        ("exp_aq", ctypes.c_void_p), ("exp_t", ctypes.c_void_p), ("exp_cls", ctypes.c_void_p),
+        ("exp_nc", ctypes.c_int), ("exp_tcount", ctypes.c_int), ("exp_dmin", ctypes.c_int),
     ]
 
 
@@ -138,6 +140,7 @@ SIGNATURES = {
     "ivit_layernorm_tokenorder_requant": [_P, _P, _L, _I, _F, _P, _P, _P, _I, _P],
     "ivit_patch_norm_tokenorder": [_P, _P, _L, _I, _F, _P, _P, _P, Dyadic, _I, _P],
     "ivit_window_attention_fused": [_P, _P, Dyadic, Dyadic, _P, _F, Dyadic, _P, _I, _I, _I, _I, _I, _I],
+    "ivit_window_attention_fused_lut": [_P, _P, Dyadic, Dyadic, _P, _F, _P, _P, _P, _I, _I, _I, Dyadic, _P, _I, _I, _I, _I, _I, _I],
     "ivit_mlp_plan_create": [_P, _P, _P, ctypes.POINTER(_P)],
     "ivit_mlp_fused_planned": [_P, _P, _P, _P, Dyadic, Dyadic, _P, _P, _L],
     "ivit_mlp_fused": [_P, _P, _P, _P, _P, _P, _P, _P, _P, Dyadic, Dyadic, _P, _P, _L, _I, _I],

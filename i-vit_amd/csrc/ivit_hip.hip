@@ -1090,9 +1090,10 @@ int ivit_embed_finish(ivit_handle h, const int16_t *patch16, const int32_t *z_cl
 
 extern "C" {
 
-int ivit_window_attention_fused(ivit_handle h, const int8_t *qkv, ivit_dyadic dy_qk, ivit_dyadic dy_a,
-                                const int16_t *relb, float s_softmax, ivit_dyadic dy_pv, int8_t *ctx, int B, int R,
-                                int window, int shift, int heads, int dh) {
+static int window_attention_impl(ivit_handle h, const int8_t *qkv, ivit_dyadic dy_qk, ivit_dyadic dy_a,
+                                 const int16_t *relb, float s_softmax, const uint16_t *aq, const float *et, const uint8_t *cls,
+                                 int nc, int t_count, int dmin, ivit_dyadic dy_pv, int8_t *ctx, int B, int R,
+                                 int window, int shift, int heads, int dh) {
     CHECK_H(h);
     REQUIRE(h, qkv && relb && ctx && B > 0 && R > 0 && heads > 0, "bad arguments");
     if (window != 7 || dh != 32 || (R % 7) != 0) {
@@ -1103,13 +1104,48 @@ int ivit_window_attention_fused(ivit_handle h, const int8_t *qkv, ivit_dyadic dy
     // magic-number rounding needs |z*c| < 2^31 with |q.k| <= 2^19 and |sum P*v| <= 2^20
     REQUIRE(h, fabs(dy_qk.m * dy_qk.r) < 2048.0 && fabs(dy_pv.m * dy_pv.r) < 1024.0, "requant factor out of range");
     WinAttnArgs a;
+    memset(&a, 0, sizeof(a));
     a.qkv = qkv; a.ctx = ctx; a.relb = relb; a.B = B; a.R = R; a.shift = shift; a.heads = heads;
     a.dy_qk = dy_qk; a.dy_a = dy_a; a.dy_pv = dy_pv; a.s = s_softmax;
     a.units = (long long)B * (R / 7) * (R / 7) * heads;
+    a.wpw = 1;
     const long long nwin = (long long)B * (R / 7) * (R / 7);
-    window_attention_kernel<<<dim3((unsigned)(((nwin + 3) / 4) * heads)), 256, 0, h->stream>>>(a);
+    if (aq) {
+        REQUIRE(h, et && cls && nc >= 1 && nc <= 64 && t_count >= 1 && t_count <= 16384 && dmin <= 0 && dmin >= -255,
+                "bad Shiftmax tables");
+        REQUIRE(h, (((uintptr_t)aq | (uintptr_t)et) & 15) == 0 && ((uintptr_t)cls & 3) == 0,
+                "Shiftmax tables: exp_aq and exp_t must be 16-byte aligned, exp_cls 4-byte aligned (copied in 16-byte pieces)");
+        a.aq = aq; a.et = et; a.cls = cls; a.nc = nc; a.t_count = t_count; a.dmin = dmin;
+        // windows per wavefront: as many as keep >= 3 workgroups per resident slot (2 per CU), at most 4
+        const long long slots = 2LL * h->num_cu;
+        int wpw = 4;
+        while (wpw > 1 && ((nwin + 8LL * wpw - 1) / (8LL * wpw)) * heads < 3 * slots) wpw >>= 1;
+        a.wpw = wpw;
+        const size_t lds = WA_FIXED(8) + (size_t)((t_count + 3) & ~3) * 4 + (size_t)nc * 512 + 256;
+        int st = set_dyn_lds(h, (const void *)window_attention_kernel<true>, lds);
+        if (st) return st;
+        window_attention_kernel<true><<<dim3((unsigned)(((nwin + 8LL * wpw - 1) / (8LL * wpw)) * heads)), 512, lds, h->stream>>>(a);
+    } else {
+        window_attention_kernel<false><<<dim3((unsigned)(((nwin + 3) / 4) * heads)), 256, WA_FIXED(4), h->stream>>>(a);
+    }
     LAUNCH_CHECK(h);
     return IVIT_OK;
+}
+
+int ivit_window_attention_fused(ivit_handle h, const int8_t *qkv, ivit_dyadic dy_qk, ivit_dyadic dy_a,
+                                const int16_t *relb, float s_softmax, ivit_dyadic dy_pv, int8_t *ctx, int B, int R,
+                                int window, int shift, int heads, int dh) {
+    return window_attention_impl(h, qkv, dy_qk, dy_a, relb, s_softmax, nullptr, nullptr, nullptr, 0, 0, 0, dy_pv, ctx, B, R,
+                                 window, shift, heads, dh);
+}
+
+int ivit_window_attention_fused_lut(ivit_handle h, const int8_t *qkv, ivit_dyadic dy_qk, ivit_dyadic dy_a,
+                                    const int16_t *relb, float s_softmax, const uint16_t *exp_aq, const float *exp_t,
+                                    const uint8_t *exp_cls, int nclass, int t_count, int dmin, ivit_dyadic dy_pv,
+                                    int8_t *ctx, int B, int R, int window, int shift, int heads, int dh) {
+    if (h && !(exp_aq && exp_t && exp_cls)) { snprintf(h->err, sizeof(h->err), "ivit_window_attention_fused_lut: null table"); return IVIT_ERR_INVALID; }
+    return window_attention_impl(h, qkv, dy_qk, dy_a, relb, s_softmax, exp_aq, exp_t, exp_cls, nclass, t_count, dmin, dy_pv, ctx,
+                                 B, R, window, shift, heads, dh);
 }
 
 int ivit_mlp_fused(ivit_handle h, const int8_t *x, const int8_t *w1, const int32_t *b1, const ivit_dyadic *dy1,

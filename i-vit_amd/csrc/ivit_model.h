@@ -387,8 +387,13 @@ int swin_run_slice(const ivit_swin_s *m, ivit_handle h, const int8_t *images, in
             const int shift = (bj % 2 == 0 || res <= c.window_size) ? 0 : c.window_size / 2;
             RUN(swin_ln(m, h, x, M, C, b.s_in, b.n1, L, li == 0, a8));
             RUN(ivit_linear_i8_requant(h, a8, b.qkv.w, b.qkv.b, b.qkv.dy, 8, qkv, (int)M, 3 * C, C));
-            RUN(ivit_window_attention_fused(h, qkv, b.dy_qk, b.dy_a, b.relb, b.s_softmax, b.dy_pv, ctx, B, res,
-                                            c.window_size, shift, heads, C / heads));
+            if (b.exp_aq)
+                RUN(ivit_window_attention_fused_lut(h, qkv, b.dy_qk, b.dy_a, b.relb, b.s_softmax, b.exp_aq, b.exp_t, b.exp_cls,
+                                                    b.exp_nc, b.exp_tcount, b.exp_dmin, b.dy_pv, ctx, B, res, c.window_size,
+                                                    shift, heads, C / heads));
+            else
+                RUN(ivit_window_attention_fused(h, qkv, b.dy_qk, b.dy_a, b.relb, b.s_softmax, b.dy_pv, ctx, B, res,
+                                                c.window_size, shift, heads, C / heads));
             RUN(ivit_linear_i8_requant_residual(h, ctx, b.proj.w, b.proj.b, b.proj.dy, b.res1_main, b.res1_res, x, y, (int)M, C, C));
             { int16_t *t = x; x = y; y = t; }
             RUN(swin_ln(m, h, x, M, C, b.s_mid, b.n2, L, li == 0, a8));

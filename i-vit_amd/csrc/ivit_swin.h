@@ -335,39 +335,73 @@ struct WinAttnArgs {
     ivit_dyadic dy_qk, dy_a, dy_pv;
     float s;                // Shiftmax input scale (qact2)
     long long units;        // B * (R/7)^2 * heads
+    // optional Shiftmax tables (ivit_amd.freeze.shiftmax_tables, as in AttnArgs) for the windows without a shift mask
+    const uint16_t *aq;     // [nc][256]
+    const float *et;        // [t_count]
+    const uint8_t *cls;     // [256]
+    int nc, t_count, dmin;
+    int wpw;                // windows per wavefront (LUT form: the tables are staged once per block)
 };
 
-__global__ __launch_bounds__(256, 4) void window_attention_kernel(WinAttnArgs p) {
-    // a block = ONE head x 4 windows: the head's relative-position slab is staged once for the four wavefronts
-    __shared__ __attribute__((aligned(16))) char sm[4 * (2048 + 64) + 4816 + 512 + 1024];
+// LUT = false: a block = ONE head x 4 windows (4 wavefronts), the head's relative-position slab staged once for the four.
+// LUT = true:  8 wavefronts x p.wpw windows each, so that the Shiftmax tables of the layer (up to 24 KB, the same for every
+//              head and window) and the slab are staged once per 8 * wpw windows; windows under the shift mask (the float
+//              -100 lives between the requotient's multiply and divide) keep the arithmetic shift-exp.
+#define WA_FIXED(NW) ((NW) * (2048 + 64) + 4816 + 512 + 1024)
+template <bool LUT>
+__global__ __launch_bounds__(LUT ? 512 : 256, 4) void window_attention_kernel(WinAttnArgs p) {
+    constexpr int NW = LUT ? 8 : 4;
+    extern __shared__ __attribute__((aligned(16))) char sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     char *sV = sm + wave * 2048;                                            // [64 keys][32 d]
-    unsigned char *sReg = reinterpret_cast<unsigned char *>(sm + 4 * 2048 + wave * 64);
-    int16_t *sRel = reinterpret_cast<int16_t *>(sm + 4 * (2048 + 64));          // [49][49], shared by the block
-    int16_t *sTa = reinterpret_cast<int16_t *>(sm + 4 * (2048 + 64) + 4816);    // rq(v, dy_a), v = -128..127
-    float *sTx = reinterpret_cast<float *>(sm + 4 * (2048 + 64) + 4816 + 512);  // fl(fl(a*s)/s)
+    unsigned char *sReg = reinterpret_cast<unsigned char *>(sm + NW * 2048 + wave * 64);
+    int16_t *sRel = reinterpret_cast<int16_t *>(sm + NW * (2048 + 64));          // [49][49], shared by the block
+    int16_t *sTa = reinterpret_cast<int16_t *>(sm + NW * (2048 + 64) + 4816);    // rq(v, dy_a), v = -128..127
+    float *sTx = reinterpret_cast<float *>(sm + NW * (2048 + 64) + 4816 + 512);  // fl(fl(a*s)/s)
+    float *sT = reinterpret_cast<float *>(sm + WA_FIXED(NW));                    // LUT: exp table, offsets, classes
+    unsigned short *sAQ = reinterpret_cast<unsigned short *>(sT + (LUT ? (p.t_count + 3) & ~3 : 0));
+    unsigned char *sCls = reinterpret_cast<unsigned char *>(sAQ + (LUT ? p.nc * 256 : 0));
     const float s = p.s;
     const RcpC sr = rcp_prepare(s);
-    {
+    if (tid < 256) {
         const double ca = p.dy_a.m * p.dy_a.r;
         sTa[tid] = (int16_t)(int)__builtin_rint((double)(tid - 128) * ca);
         sTx[tid] = requotient_c((float)(tid - 128), sr);
+    }
+    if (LUT) {
+        const int n4 = p.t_count >> 2, a4 = p.nc * 32;          // whole 16-byte chunks (alignment checked by the launcher)
+        for (int i = tid; i < n4; i += NW * 64) reinterpret_cast<v4i *>(sT)[i] = reinterpret_cast<const v4i *>(p.et)[i];
+        if (tid < (p.t_count & 3)) sT[(n4 << 2) + tid] = p.et[(n4 << 2) + tid];
+        // offsets staged as byte offsets into sT (x4; t_count <= 16384 keeps them in 16 bits)
+        for (int i = tid; i < a4; i += NW * 64) {
+            v4i t = reinterpret_cast<const v4i *>(p.aq)[i];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) t[u] = (int)(((unsigned)t[u] & 0x3fff3fffu) << 2);
+            *reinterpret_cast<v4i *>(reinterpret_cast<char *>(sAQ) + i * 16) = t;
+        }
+        if (tid < 64) reinterpret_cast<unsigned *>(sCls)[tid] = reinterpret_cast<const unsigned *>(p.cls)[tid];
     }
     const int head = (int)(blockIdx.x % p.heads);
     {
         const unsigned *rb = reinterpret_cast<const unsigned *>(p.relb + (long long)head * 2401);   // 2401 int16: 1200 dwords + 1
         const bool al = ((head * 2401) & 1) == 0;              // odd heads start on a 2-byte boundary
         if (al) {
-            for (int i = tid; i < 1200; i += 256) reinterpret_cast<unsigned *>(sRel)[i] = rb[i];
+            for (int i = tid; i < 1200; i += NW * 64) reinterpret_cast<unsigned *>(sRel)[i] = rb[i];
             if (tid == 0) sRel[2400] = p.relb[(long long)head * 2401 + 2400];
         } else {
-            for (int i = tid; i < 2401; i += 256) sRel[i] = p.relb[(long long)head * 2401 + i];
+            for (int i = tid; i < 2401; i += NW * 64) sRel[i] = p.relb[(long long)head * 2401 + i];
         }
     }
     __syncthreads();
     const int R = p.R, nw = R / 7, C = p.heads * 32;
-    const long long wlin = (long long)(blockIdx.x / p.heads) * 4 + wave;
+    const int wpw = LUT ? p.wpw : 1;
+    for (int it = 0; it < wpw; ++it) {       // no workgroup barrier below: the wavefronts run their windows independently
+    const long long wlin = ((long long)(blockIdx.x / p.heads) * wpw + it) * NW + wave;
     if (wlin >= (long long)p.B * nw * nw) return;
+    if (LUT && it) {                         // this wavefront's V rows / regions of the previous window are dead now
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
     const int win = (int)(wlin % (nw * nw)), b = (int)(wlin / (nw * nw));
     const int wi = win / nw, wj = win - wi * nw;
     auto tok_off = [&](int n) -> long long {                 // natural token index of window token n
@@ -441,29 +475,63 @@ __global__ __launch_bounds__(256, 4) void window_attention_kernel(WinAttnArgs p)
         // valid keys: tile 0 all 16 registers; tile 1 registers 0..7 (keys 32..47) and, for half 0, r = 8 (key 48)
         float f[25];
         const int regq = sReg[qq];
-        float mx = -INFINITY;
-#pragma unroll
-        for (int i = 0; i < 25; ++i) {
+        auto score = [&](int i, int &kk) -> int {         // a = clamp8(rq(clamp8(rq(S, dy_qk)), dy_a) + relb)
             const int kt = i < 16 ? 0 : 1, r = i < 16 ? i : i - 16;
             const int key = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * half;      // < 49 except i == 24 on half 1
-            const int kk = (i == 24 && half) ? 48 : key;
+            kk = (i == 24 && half) ? 48 : key;
             const int z = kt ? acc1[r] : acc0[r];
             const int v = min(max(__double2loint((double)z * c_qk + 6755399441055744.0), -128), 127);
-            const int a = min(max((int)sTa[v + 128] + (int)sRel[qq * 49 + kk], -128), 127);
-            float xt;
-            if (masked) {
-                float X = (float)a * s;
-                X = X + ((sReg[kk] != regq) ? -100.0f : 0.0f);
-                xt = lean_div(X, sr);
-            } else {
-                xt = sTx[a + 128];
-            }
-            f[i] = xt;
-            if (!(i == 24 && half)) mx = fmaxf(mx, xt);
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+            return min(max((int)sTa[v + 128] + (int)sRel[qq * 49 + kk], -128), 127);
+        };
+        if (LUT && !masked) {
+            // exp_int by table: e = et[aq[class(amax)][a] + max(a - amax, dmin) - dmin] (ivit_attention.h has the derivation);
+            // fl(fl(a*s)/s) is monotone in a, so the row maximum is taken on the integers
+            int av[25], amax = -128;
 #pragma unroll
-        for (int i = 0; i < 25; ++i) f[i] = shift_exp_nonpos(f[i] - mx, x0r, nx0, 15);
+            for (int i = 0; i < 25; ++i) {
+                int kk;
+                av[i] = score(i, kk);
+                if (!(i == 24 && half)) amax = max(amax, av[i]);
+                if (i == 8 || i == 16) __builtin_amdgcn_sched_barrier(0);     // three batches of gathers: bounded live registers
+            }
+            amax = max(amax, __shfl_xor(amax, 32));
+            typedef __attribute__((address_space(3))) const char wa_lds_c;
+            const unsigned aqrow = (unsigned)(size_t)((wa_lds_c *)sAQ) + ((unsigned)sCls[amax + 128] * 256u + 128u) * 2u;
+            const unsigned tb = (unsigned)(size_t)((wa_lds_c *)sT);
+            const int qd = amax + p.dmin;
+#pragma unroll
+            for (int c0 = 0; c0 < 25; c0 += 13) {
+                int e1[13];
+#pragma unroll
+                for (int i = c0; i < c0 + 13 && i < 25; ++i)
+                    e1[i - c0] = (int)*reinterpret_cast<__attribute__((address_space(3))) const unsigned short *>((size_t)(aqrow + (unsigned)(av[i] << 1)));
+#pragma unroll
+                for (int i = c0; i < c0 + 13 && i < 25; ++i)
+                    f[i] = *reinterpret_cast<__attribute__((address_space(3))) const float *>(
+                        (size_t)(tb + (unsigned)e1[i - c0] + ((unsigned)max(av[i] - qd, 0) << 2)));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 25; ++i) {
+                int kk;
+                const int a = score(i, kk);
+                float xt;
+                if (masked) {
+                    float X = (float)a * s;
+                    X = X + ((sReg[kk] != regq) ? -100.0f : 0.0f);
+                    xt = lean_div(X, sr);
+                } else {
+                    xt = sTx[a + 128];
+                }
+                f[i] = xt;
+                if (!(i == 24 && half)) mx = fmaxf(mx, xt);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+#pragma unroll
+            for (int i = 0; i < 25; ++i) f[i] = shift_exp_nonpos(f[i] - mx, x0r, nx0, 15);
+        }
         // torch-order row sum (n = 49), lane-local partials for l = 4*half + e
         float pl[4];
 #pragma unroll
@@ -514,6 +582,7 @@ __global__ __launch_bounds__(256, 4) void window_attention_kernel(WinAttnArgs p)
         auto s13 = __builtin_amdgcn_permlane32_swap(W[1], W[3], false, false);
         const v4i outv = {(int)s02[0], (int)s02[1], (int)s13[0], (int)s13[1]};   // d = 16*half .. +16
         if (qlive) *reinterpret_cast<v4i *>(p.ctx + tok_off(q) * C + head * 32 + half * 16) = outv;
+    }
     }
 }
 

@@ -21,7 +21,7 @@ import torch
 
 from . import _lib
 from .engine import pack_constants
-from .freeze import dyadic, layernorm_constants, quantize, quantize_bias, quantize_weight
+from .freeze import dyadic, layernorm_constants, quantize, quantize_bias, quantize_weight, shiftmax_tables
 
 _P = ctypes.c_void_p
 
@@ -41,8 +41,11 @@ def _rne_times(z, dy):
     return np.rint(z.astype(np.float64) * dy[0, 0] * dy[0, 1])
 
 
-def freeze_swin(cfg, weights, scales):
-    """name -> numpy array / python scalar for every constant of the frozen Swin."""
+def freeze_swin(cfg, weights, scales, exp_tables=False):
+    """name -> numpy array / python scalar for every constant of the frozen Swin.
+    exp_tables: also build the Shiftmax tables of every layer, which routes the windowed attention to
+    ivit_window_attention_fused_lut.  Off by default: measured on MI355X the table form is not faster than the
+    arithmetic one in this kernel (profiles/README.md, round 4) — the switch keeps the path exercised by the tests."""
     s = {k: np.float32(v) for k, v in scales.items()}
     c = {}
 
@@ -90,6 +93,11 @@ def freeze_swin(cfg, weights, scales):
             c[p + "attn.relb"] = np.ascontiguousarray(
                 _rne_times(bias, dyadic(s[p + "attn.qact_table"], s[p + "attn.qact2"]))).astype(np.int16)
             c[p + "attn.s_softmax"] = s[p + "attn.qact2"]
+            tabs = shiftmax_tables(s[p + "attn.qact2"]) if exp_tables else None   # exp_int by table where no shift mask applies
+            if tabs is not None:                               # else: the kernel's arithmetic path for this layer
+                c[p + "attn.exp_aq"], c[p + "attn.exp_t"], c[p + "attn.exp_cls"] = tabs["aq"], tabs["t"], tabs["cls"]
+                # three small integers, carried with the fp32 host scalars (exact: t_count <= 16384)
+                c[p + "attn.exp_nc"], c[p + "attn.exp_tcount"], c[p + "attn.exp_dmin"] = tabs["NC"], tabs["t"].size, tabs["dmin"]
             c[p + "attn.dy_pv"] = dyadic(np.float32(np.float32(2.0 ** -7) * s1), s[p + "attn.qact3"])
             linear(p + "attn.proj", s[p + "attn.qact3"], p + "attn.qact4")
             c[p + "res1.dy_main"] = dyadic(s[p + "attn.qact4"], s[p + "qact2"])
@@ -158,6 +166,10 @@ def swin_native_params(cfg, table, f, dy, base):
             b.s_in, b.n1, b.qkv = f[p + "s_in"], ln(p + "norm1"), lin(p + "attn.qkv")
             b.dy_qk, b.dy_a, b.relb = dy[p + "attn.dy_qk"], dy[p + "attn.dy_a"], a(p + "attn.relb")
             b.s_softmax, b.dy_pv, b.proj = f[p + "attn.s_softmax"], dy[p + "attn.dy_pv"], lin(p + "attn.proj")
+            if p + "attn.exp_aq" in table:
+                b.exp_aq, b.exp_t, b.exp_cls = a(p + "attn.exp_aq"), a(p + "attn.exp_t"), a(p + "attn.exp_cls")
+                b.exp_nc, b.exp_tcount, b.exp_dmin = (int(f[p + "attn.exp_nc"]), int(f[p + "attn.exp_tcount"]),
+                                                      int(f[p + "attn.exp_dmin"]))
             b.res1_main, b.res1_res = dy[p + "res1.dy_main"], dy[p + "res1.dy_res"]
             b.s_mid, b.n2, b.fc1 = f[p + "s_mid"], ln(p + "norm2"), lin(p + "mlp.fc1")
             b.s_gelu, b.dy_gelu, b.fc2 = f[p + "mlp.s_gelu"], dy[p + "mlp.dy_gelu"], lin(p + "mlp.fc2")
@@ -179,15 +191,16 @@ def swin_native_params(cfg, table, f, dy, base):
 
 
 class SwinEngine:
-    def __init__(self, cfg, weights, scales, device="cuda:0", packed=None):
-        """weights/scales: freeze here (rank 0) — or `packed` = (blob, table, host) received from a broadcast."""
+    def __init__(self, cfg, weights, scales, device="cuda:0", packed=None, exp_tables=False):
+        """weights/scales: freeze here (rank 0) — or `packed` = (blob, table, host) received from a broadcast.
+        exp_tables: see freeze_swin."""
         if not torch.cuda.is_available():
             raise _lib.IvitError("SwinEngine needs a HIP device; the product path has no CPU fallback")
         self.cfg, self.device = cfg, torch.device(device)
         torch.cuda.set_device(self.device)
         if cfg.window_size != 7 or any((cfg.embed_dim * 2 ** i) // h != 32 for i, h in enumerate(cfg.num_heads)):
             raise _lib.IvitError("the fused windowed attention is built for window 7 / head dim 32")
-        blob, table, host = packed if packed is not None else pack_swin_constants(freeze_swin(cfg, weights, scales))
+        blob, table, host = packed if packed is not None else pack_swin_constants(freeze_swin(cfg, weights, scales, exp_tables))
         self.table, self.host_consts = table, host
         self.blob = torch.from_numpy(blob).to(self.device) if isinstance(blob, np.ndarray) else blob.to(self.device)
         o, dt, shp = table["head.scale"]
@@ -206,6 +219,7 @@ class SwinEngine:
                 self.h.call("ivit_shiftgelu_build_table", self.f[p + "mlp.s_gelu"], self.dy[p + "mlp.dy_gelu"], _P(tab.data_ptr()))
                 self.gelu[p] = tab
         self._ws = {}
+        self.use_exp_tables = True      # forward_ops only: False issues the arithmetic Shiftmax in every window (cross-check)
 
     MAX_SLICES = 8
 
@@ -324,9 +338,16 @@ class SwinEngine:
                 self._ln(x, M, C, f[p + "s_in"], p + "norm1", L, li == 0, ws["a8"])
                 call("ivit_linear_i8_requant", P(ws["a8"]), self.ptr(p + "attn.qkv.w"), self.ptr(p + "attn.qkv.b"),
                      self.ptr(p + "attn.qkv.dy"), 8, P(ws["qkv"]), M, 3 * C, C)
-                call("ivit_window_attention_fused", P(ws["qkv"]), dy[p + "attn.dy_qk"], dy[p + "attn.dy_a"],
-                     self.ptr(p + "attn.relb"), f[p + "attn.s_softmax"], dy[p + "attn.dy_pv"], P(ws["ctx"]),
-                     B, res, cfg.window_size, shift, heads, C // heads)
+                if p + "attn.exp_aq" in self.table and self.use_exp_tables:
+                    call("ivit_window_attention_fused_lut", P(ws["qkv"]), dy[p + "attn.dy_qk"], dy[p + "attn.dy_a"],
+                         self.ptr(p + "attn.relb"), f[p + "attn.s_softmax"], self.ptr(p + "attn.exp_aq"),
+                         self.ptr(p + "attn.exp_t"), self.ptr(p + "attn.exp_cls"), int(f[p + "attn.exp_nc"]),
+                         int(f[p + "attn.exp_tcount"]), int(f[p + "attn.exp_dmin"]), dy[p + "attn.dy_pv"], P(ws["ctx"]),
+                         B, res, cfg.window_size, shift, heads, C // heads)
+                else:
+                    call("ivit_window_attention_fused", P(ws["qkv"]), dy[p + "attn.dy_qk"], dy[p + "attn.dy_a"],
+                         self.ptr(p + "attn.relb"), f[p + "attn.s_softmax"], dy[p + "attn.dy_pv"], P(ws["ctx"]),
+                         B, res, cfg.window_size, shift, heads, C // heads)
                 call("ivit_linear_i8_requant_residual", P(ws["ctx"]), self.ptr(p + "attn.proj.w"), self.ptr(p + "attn.proj.b"),
                      self.ptr(p + "attn.proj.dy"), dy[p + "res1.dy_main"], dy[p + "res1.dy_res"], P(x), P(y), M, C, C)
                 x, y = y, x

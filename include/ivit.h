@@ -323,6 +323,8 @@ typedef struct ivit_swin_block {
     float s_mid; ivit_ln_params n2;                        /* norm2 -> qact3 (:291-292)                         */
     ivit_lin_params fc1; float s_gelu; ivit_dyadic dy_gelu; ivit_lin_params fc2;   /* mlp (layers_quant.py:144-153) */
     ivit_dyadic res2_main, res2_res;                       /* qact4 with identity (:296)                        */
+    const uint16_t *exp_aq; const float *exp_t; const uint8_t *exp_cls;   /* optional Shiftmax tables for s_softmax (NULL: arithmetic) */
+    int exp_nc, exp_tcount, exp_dmin;
 } ivit_swin_block;
 
 typedef struct ivit_swin_merge {                           /* PatchMerging: norm -> qact1 -> reduction -> qact2 */
@@ -390,6 +392,14 @@ int ivit_patch_norm_tokenorder(ivit_handle h, const int8_t *x8, int64_t rows, in
 int ivit_window_attention_fused(ivit_handle h, const int8_t *qkv, ivit_dyadic dy_qk, ivit_dyadic dy_a,
                                 const int16_t *relb, float s_softmax, ivit_dyadic dy_pv, int8_t *ctx,
                                 int B, int R, int window, int shift, int heads, int dh);
+/* The same with Shiftmax's exp_int (IntSoftmax.int_exp_shift, quant_modules.py:469-481) taken from the tables of
+ * ivit_attention_fused_lut (ivit_amd.freeze.shiftmax_tables for the layer's frozen qact2 scale; same layout, alignment and
+ * errors) in the windows that carry no shift mask; windows under the mask (swin_quant.py:151-156) keep the arithmetic
+ * form, because the float -100 enters between the requotient's multiply and divide.  Same integers as the entry above. */
+int ivit_window_attention_fused_lut(ivit_handle h, const int8_t *qkv, ivit_dyadic dy_qk, ivit_dyadic dy_a,
+                                    const int16_t *relb, float s_softmax, const uint16_t *exp_aq, const float *exp_t,
+                                    const uint8_t *exp_cls, int nclass, int t_count, int dmin, ivit_dyadic dy_pv,
+                                    int8_t *ctx, int B, int R, int window, int shift, int heads, int dh);
 /* Fused Mlp.forward + closing QuantAct(identity) for a narrow stage (layers_quant.py:144-153,
  * swin_quant.py:293-296): fc1 -> qact_gelu(8) -> ShiftGELU -> qact1(8) -> fc2 -> qact2(16) -> qact4(16, +identity)
  * with both weight matrices resident in LDS and the hidden tensor never written to HBM.

@@ -555,6 +555,15 @@ int ivit_cpu_window_attention_fused(ivit_handle h, const int8_t *qkv, ivit_dyadi
     return TW_OK;
 }
 
+/* the table form computes the same integers (the tables are checked exhaustively against the arithmetic when built) */
+int ivit_cpu_window_attention_fused_lut(ivit_handle h, const int8_t *qkv, ivit_dyadic dy_qk, ivit_dyadic dy_a, const int16_t *relb,
+                                        float s_softmax, const uint16_t *exp_aq, const float *exp_t, const uint8_t *exp_cls,
+                                        int nclass, int t_count, int dmin, ivit_dyadic dy_pv, int8_t *ctx, int B, int R,
+                                        int window, int shift, int heads, int dh) {
+    TW_REQ(exp_aq && exp_t && exp_cls && nclass >= 1 && t_count >= 1 && dmin <= 0);
+    return ivit_cpu_window_attention_fused(h, qkv, dy_qk, dy_a, relb, s_softmax, dy_pv, ctx, B, R, window, shift, heads, dh);
+}
+
 /* planned fused Mlp: the twin keeps the two linear plans; the planned call is the unplanned chain */
 struct ivit_cpu_mlp_plan_s { const struct ivit_cpu_plan_s *fc1, *fc2; };
 int ivit_cpu_mlp_plan_create(ivit_handle h, ivit_linear_plan fc1, ivit_linear_plan fc2, ivit_mlp_plan *out) {
@@ -784,7 +793,11 @@ int ivit_cpu_swin_forward(ivit_swin m, const int8_t *images, int batch, int nsli
             if (li == 0) TW_RUN(ivit_cpu_layernorm_tokenorder_requant(NULL, x, M, C, b->s_in, b->n1.bias_int, b->n1.sc, b->n1.dy, L, a8));
             else TW_RUN(ivit_cpu_layernorm_requant(NULL, x, M, C, C, b->s_in, b->n1.bias_int, b->n1.sc, b->n1.dy, a8));
             TW_RUN(ivit_cpu_linear_i8_requant(NULL, a8, b->qkv.w, b->qkv.b, b->qkv.dy, 8, qkv, (int)M, 3 * C, C));
-            TW_RUN(ivit_cpu_window_attention_fused(NULL, qkv, b->dy_qk, b->dy_a, b->relb, b->s_softmax, b->dy_pv, ctx, B, res, c->window_size, shift, heads, C / heads));
+            if (b->exp_aq)
+                TW_RUN(ivit_cpu_window_attention_fused_lut(NULL, qkv, b->dy_qk, b->dy_a, b->relb, b->s_softmax, b->exp_aq, b->exp_t, b->exp_cls, b->exp_nc,
+                                                           b->exp_tcount, b->exp_dmin, b->dy_pv, ctx, B, res, c->window_size, shift, heads, C / heads));
+            else
+                TW_RUN(ivit_cpu_window_attention_fused(NULL, qkv, b->dy_qk, b->dy_a, b->relb, b->s_softmax, b->dy_pv, ctx, B, res, c->window_size, shift, heads, C / heads));
             TW_RUN(ivit_cpu_linear_i8_requant_residual(NULL, ctx, b->proj.w, b->proj.b, b->proj.dy, b->res1_main, b->res1_res, x, y, (int)M, C, C));
             { int16_t *t = x; x = y; y = t; }
             if (li == 0) TW_RUN(ivit_cpu_layernorm_tokenorder_requant(NULL, x, M, C, b->s_mid, b->n2.bias_int, b->n2.sc, b->n2.dy, L, a8));

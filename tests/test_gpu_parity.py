@@ -530,6 +530,11 @@ def test_swin_engine_golden_logits(fname):
         imgs2 = iv.make_images_int8(cfg, 5, seed=123)
         ref, _ = orc.OracleSwin(cfg, w, golden_scales(g)).forward(imgs2)
         assert np.array_equal(eng.forward(dev(imgs2)).cpu().numpy(), ref)
+    # the table form of the windowed attention (off by default: not faster on MI355X) through both runners
+    eng_t = SwinEngine(cfg, w, golden_scales(g), exp_tables=True)
+    assert any(k.endswith("attn.exp_aq") for k in eng_t.table)
+    assert np.array_equal(eng_t.forward(dev(imgs)).cpu().numpy(), g["logits_int"])
+    assert np.array_equal(eng_t.forward_ops(dev(imgs)).cpu().numpy(), g["logits_int"])
 
 
 @pytest.mark.parametrize("M", [80 * 256 - 1, 80 * 256 + 1, 25216])
@@ -892,6 +897,32 @@ def test_attention_shiftmax_tables_equal_arithmetic(H, scale):
         H.call("ivit_attention_fused_lut", P(q), P(k), P(vt), dyv(dqk), float(scale), P(dev(tabs["aq"])),
                ctypes.c_void_p(shifted.data_ptr() + 4), P(dev(tabs["cls"])), int(tabs["NC"]), int(tabs["t"].size),
                int(tabs["dmin"]), dyv(dpv), P(o2), B, Hh, T, dh, ld)
+
+
+@pytest.mark.parametrize("scale", [0.06, 0.0431, 0.1947])
+def test_window_attention_shiftmax_tables_equal_arithmetic(H, scale):
+    """ivit_window_attention_fused_lut (exp_int from freeze.shiftmax_tables in the windows without a shift mask, arithmetic
+    under the mask) == ivit_window_attention_fused, with and without the cyclic shift, on grids whose window count makes the
+    launcher pick 1, 2 and 4 windows per wavefront (ragged against 8 * wpw)."""
+    tabs = iv.freeze.shiftmax_tables(np.float32(scale))
+    assert tabs is not None
+    rng = np.random.default_rng(int(scale * 1e4))
+    aq, et, cl = dev(tabs["aq"]), dev(tabs["t"]), dev(tabs["cls"])
+    dqk = iv.freeze.dyadic(np.float32(3.1e-4), np.float32(scale * 0.8))
+    da = iv.freeze.dyadic(np.float32(scale * 0.8), np.float32(scale))
+    dpv = iv.freeze.dyadic(np.float32(4e-4), np.float32(0.03))
+    for B, R, Hh in ((3, 28, 3), (5, 14, 6), (130, 56, 3), (257, 56, 3)):
+        qkv = torch.randint(-128, 128, (B, R, R, 3 * Hh * 32), dtype=torch.int8, device="cuda",
+                            generator=torch.Generator(device="cuda").manual_seed(B * R))
+        relb = dev(rng.integers(-60, 60, (Hh, 49, 49)).astype(np.int16))
+        for sh in (0, 3):
+            o1 = torch.empty(B, R * R, Hh * 32, dtype=torch.int8, device="cuda")
+            o2 = torch.full_like(o1, 9)
+            H.call("ivit_window_attention_fused", P(qkv), dyv(dqk), dyv(da), P(relb), float(scale), dyv(dpv), P(o1), B, R, 7, sh, Hh, 32)
+            H.call("ivit_window_attention_fused_lut", P(qkv), dyv(dqk), dyv(da), P(relb), float(scale), P(aq), P(et), P(cl),
+                   int(tabs["NC"]), int(tabs["t"].size), int(tabs["dmin"]), dyv(dpv), P(o2), B, R, 7, sh, Hh, 32)
+            assert torch.equal(o1, o2), (scale, B, R, sh)
+        assert len(torch.unique(o1)) > 20
 
 
 # ---------------------------------------------------------------- persistent pipelined GEMMs (csrc/ivit_gemm3.h)

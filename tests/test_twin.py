@@ -214,6 +214,11 @@ def _cases(rng, variant=0):
     for sh in (0, 3):
         cs.append(("window_attention_fused", [I(qkvw), dyv(dwq), dyv(dwa), I(relb), (0.06, 0.071)[V], dyv(dwp), O(np.zeros((Bw, Rw * Rw, Hw * 32), np.int8)),
                                               Bw, Rw, 7, sh, Hw, 32]))
+    wtab = iv.freeze.shiftmax_tables(np.float32((0.06, 0.071)[V]))
+    for sh in (0, 3):
+        cs.append(("window_attention_fused_lut", [I(qkvw), dyv(dwq), dyv(dwa), I(relb), (0.06, 0.071)[V], I(wtab["aq"]), I(wtab["t"]), I(wtab["cls"]),
+                                                  int(wtab["NC"]), int(wtab["t"].size), int(wtab["dmin"]), dyv(dwp),
+                                                  O(np.zeros((Bw, Rw * Rw, Hw * 32), np.int8)), Bw, Rw, 7, sh, Hw, 32]))
     # ---- the uint8 front end (N3): ToTensor -> Normalize -> input QuantAct; antialiased bicubic resize + centre crop
     u8 = rng.integers(0, 256, (2, 37, 53, 3), dtype=np.uint8)
     u8.reshape(-1)[:256] = np.arange(256, dtype=np.uint8)
@@ -426,10 +431,10 @@ def _twin_vit(twin, g, images):
     return logits
 
 
-def _twin_swin(twin, g, images):
+def _twin_swin(twin, g, images, exp_tables=False):
     from ivit_amd import swin_engine as S
     cfg = iv.SWIN_CONFIGS[str(g["cfg_name"])]
-    blob, table, host = S.pack_swin_constants(S.freeze_swin(cfg, iv.make_swin_weights(cfg, int(g["seed"])), golden_scales(g)))
+    blob, table, host = S.pack_swin_constants(S.freeze_swin(cfg, iv.make_swin_weights(cfg, int(g["seed"])), golden_scales(g), exp_tables))
     f, dy = S.swin_host_scalars(host)
     c, prm, keep = S.swin_native_params(cfg, table, f, dy, blob.ctypes.data)
     m = _P()
@@ -462,6 +467,8 @@ def test_twin_swin_runner_matches_reference_golden(twin, fname):
     cfg = iv.SWIN_CONFIGS[str(g["cfg_name"])]
     imgs = iv.make_images_int8(cfg, int(g["batch"]), int(g["images_seed"]))
     assert np.array_equal(_twin_swin(twin, g, imgs), g["logits_int"])
+    if fname.startswith("micro"):       # and with the per-layer Shiftmax tables in the block structs (ivit_cpu_window_attention_fused_lut)
+        assert np.array_equal(_twin_swin(twin, g, imgs, exp_tables=True), g["logits_int"])
 
 
 @pytest.mark.gpu
