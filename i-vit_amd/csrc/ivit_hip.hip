@@ -1124,9 +1124,11 @@ static int window_attention_impl(ivit_handle h, const int8_t *qkv, ivit_dyadic d
         const size_t lds = WA_FIXED(8) + (size_t)((t_count + 3) & ~3) * 4 + (size_t)nc * 512 + 256;
         int st = set_dyn_lds(h, (const void *)window_attention_kernel<true>, lds);
         if (st) return st;
-        window_attention_kernel<true><<<dim3((unsigned)(((nwin + 8LL * wpw - 1) / (8LL * wpw)) * heads)), 512, lds, h->stream>>>(a);
+        const long long groups = (nwin + 8LL * wpw - 1) / (8LL * wpw);      // grid: whole groups of 8 window groups (see the kernel)
+        window_attention_kernel<true><<<dim3((unsigned)(((groups + 7) / 8) * 8 * heads)), 512, lds, h->stream>>>(a);
     } else {
-        window_attention_kernel<false><<<dim3((unsigned)(((nwin + 3) / 4) * heads)), 256, WA_FIXED(4), h->stream>>>(a);
+        const long long groups = (nwin + 3) / 4;
+        window_attention_kernel<false><<<dim3((unsigned)(((groups + 7) / 8) * 8 * heads)), 256, WA_FIXED(4), h->stream>>>(a);
     }
     LAUNCH_CHECK(h);
     return IVIT_OK;

@@ -347,6 +347,9 @@ struct WinAttnArgs {
 // LUT = true:  8 wavefronts x p.wpw windows each, so that the Shiftmax tables of the layer (up to 24 KB, the same for every
 //              head and window) and the slab are staged once per 8 * wpw windows; windows under the shift mask (the float
 //              -100 lives between the requotient's multiply and divide) keep the arithmetic shift-exp.
+#ifndef WA_PROBE          // timing probes only (results invalid): 1 no shift-exp arithmetic, 2 no score gathers (requant only),
+#define WA_PROBE 0         // 4 no global stores, 8 return after the operand loads
+#endif
 #define WA_FIXED(NW) ((NW) * (2048 + 64) + 4816 + 512 + 1024)
 template <bool LUT>
 __global__ __launch_bounds__(LUT ? 512 : 256, 4) void window_attention_kernel(WinAttnArgs p) {
@@ -381,22 +384,41 @@ __global__ __launch_bounds__(LUT ? 512 : 256, 4) void window_attention_kernel(Wi
         }
         if (tid < 64) reinterpret_cast<unsigned *>(sCls)[tid] = reinterpret_cast<const unsigned *>(p.cls)[tid];
     }
-    const int head = (int)(blockIdx.x % p.heads);
+    // Block -> (window group, head): the heads of one window group sit 8 block ids apart, i.e. on ONE XCD and close in time.
+    // A token's q | k | v row is 3 * heads * 32 contiguous bytes of which a block reads 32-byte pieces; with head-fastest block
+    // ids the 3 ... 24 heads of a window ran on different XCDs and every L2 fetched the same lines (round 3 counters: 3.5x the
+    // algorithmic bytes from HBM; the operand loads alone were 91 of the stage-0 launch's 215 us).
+    const int xcd = (int)(blockIdx.x & 7), bq = (int)(blockIdx.x >> 3);
+    const int head = bq % p.heads;
+    const long long wgrp = (long long)(bq / p.heads) * 8 + xcd;
+    if (wgrp * (LUT ? p.wpw : 1) * NW >= (long long)p.B * (p.R / 7) * (p.R / 7)) return;      // padding blocks of the last group of 8
     {
         const unsigned *rb = reinterpret_cast<const unsigned *>(p.relb + (long long)head * 2401);   // 2401 int16: 1200 dwords + 1
         const bool al = ((head * 2401) & 1) == 0;              // odd heads start on a 2-byte boundary
+        // every load of the slab is issued before the first one is stored (as a load-store loop it was 5 / 10 serial memory
+        // latencies per block)
         if (al) {
-            for (int i = tid; i < 1200; i += NW * 64) reinterpret_cast<unsigned *>(sRel)[i] = rb[i];
+            constexpr int NI = (1200 + NW * 64 - 1) / (NW * 64);
+            unsigned t[NI];
+#pragma unroll
+            for (int u = 0; u < NI; ++u) if (tid + u * NW * 64 < 1200) t[u] = rb[tid + u * NW * 64];
+#pragma unroll
+            for (int u = 0; u < NI; ++u) if (tid + u * NW * 64 < 1200) reinterpret_cast<unsigned *>(sRel)[tid + u * NW * 64] = t[u];
             if (tid == 0) sRel[2400] = p.relb[(long long)head * 2401 + 2400];
         } else {
-            for (int i = tid; i < 2401; i += NW * 64) sRel[i] = p.relb[(long long)head * 2401 + i];
+            constexpr int NI = (2401 + NW * 64 - 1) / (NW * 64);
+            int16_t t[NI];
+#pragma unroll
+            for (int u = 0; u < NI; ++u) if (tid + u * NW * 64 < 2401) t[u] = p.relb[(long long)head * 2401 + tid + u * NW * 64];
+#pragma unroll
+            for (int u = 0; u < NI; ++u) if (tid + u * NW * 64 < 2401) sRel[tid + u * NW * 64] = t[u];
         }
     }
     __syncthreads();
     const int R = p.R, nw = R / 7, C = p.heads * 32;
     const int wpw = LUT ? p.wpw : 1;
     for (int it = 0; it < wpw; ++it) {       // no workgroup barrier below: the wavefronts run their windows independently
-    const long long wlin = ((long long)(blockIdx.x / p.heads) * wpw + it) * NW + wave;
+    const long long wlin = (wgrp * wpw + it) * NW + wave;
     if (wlin >= (long long)p.B * nw * nw) return;
     if (LUT && it) {                         // this wavefront's V rows / regions of the previous window are dead now
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -457,6 +479,7 @@ __global__ __launch_bounds__(LUT ? 512 : 256, 4) void window_attention_kernel(Wi
             vf[kt][w] = (int)word;
         }
 
+    if ((WA_PROBE & 8) && (vf[0][0] ^ vf[1][3] ^ qf[0][0] ^ kf[1][1]) != 0x12345678) return;
     const double c_qk = p.dy_qk.m * p.dy_qk.r, c_pv = p.dy_pv.m * p.dy_pv.r;
     const float x0 = floorf(-1.0f / s), nx0 = 15.0f * x0;
     const RcpC x0r = rcp_prepare(x0);
@@ -481,6 +504,7 @@ __global__ __launch_bounds__(LUT ? 512 : 256, 4) void window_attention_kernel(Wi
             kk = (i == 24 && half) ? 48 : key;
             const int z = kt ? acc1[r] : acc0[r];
             const int v = min(max(__double2loint((double)z * c_qk + 6755399441055744.0), -128), 127);
+            if (WA_PROBE & 2) return v;
             return min(max((int)sTa[v + 128] + (int)sRel[qq * 49 + kk], -128), 127);
         };
         if (LUT && !masked) {
@@ -530,7 +554,7 @@ __global__ __launch_bounds__(LUT ? 512 : 256, 4) void window_attention_kernel(Wi
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32));
 #pragma unroll
-            for (int i = 0; i < 25; ++i) f[i] = shift_exp_nonpos(f[i] - mx, x0r, nx0, 15);
+            for (int i = 0; i < 25; ++i) f[i] = (WA_PROBE & 1) ? f[i] - mx : shift_exp_nonpos(f[i] - mx, x0r, nx0, 15);
         }
         // torch-order row sum (n = 49), lane-local partials for l = 4*half + e
         float pl[4];
@@ -581,7 +605,7 @@ __global__ __launch_bounds__(LUT ? 512 : 256, 4) void window_attention_kernel(Wi
         auto s02 = __builtin_amdgcn_permlane32_swap(W[0], W[2], false, false);
         auto s13 = __builtin_amdgcn_permlane32_swap(W[1], W[3], false, false);
         const v4i outv = {(int)s02[0], (int)s02[1], (int)s13[0], (int)s13[1]};   // d = 16*half .. +16
-        if (qlive) *reinterpret_cast<v4i *>(p.ctx + tok_off(q) * C + head * 32 + half * 16) = outv;
+        if (qlive && (!(WA_PROBE & 4) || outv[0] == 0x12345678)) *reinterpret_cast<v4i *>(p.ctx + tok_off(q) * C + head * 32 + half * 16) = outv;
     }
     }
 }
