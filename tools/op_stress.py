@@ -143,6 +143,11 @@ if not os.environ.get("SWIN_ONLY"):
     dqkv, dpvv = iv.freeze.dyadic(np.float32(2e-4), np.float32(6e-2)), iv.freeze.dyadic(np.float32(3e-6), np.float32(9e-3))
     stress("ivit_attention_fused T=197", lambda: torch.empty(Bv, T, D, dtype=torch.int8, device="cuda"),
            lambda h, o: h.call("ivit_attention_fused", P(qv), P(kv), P(vtv), dyv(dqkv), 0.06, dyv(dpvv), P(o), Bv, Hh, T, 64, ldv), None)
+    etab = iv.freeze.shiftmax_tables(np.float32(0.06))
+    eaq, eet, ecl = dev(etab["aq"]), dev(etab["t"]), dev(etab["cls"])
+    stress("ivit_attention_fused_lut T=197", lambda: torch.empty(Bv, T, D, dtype=torch.int8, device="cuda"),
+           lambda h, o: h.call("ivit_attention_fused_lut", P(qv), P(kv), P(vtv), dyv(dqkv), 0.06, P(eaq), P(eet), P(ecl), int(etab["NC"]),
+                               int(etab["t"].size), int(etab["dmin"]), dyv(dpvv), P(o), Bv, Hh, T, 64, ldv), None)
     imgv = dev(rng.integers(-128, 128, (Bv, 3, 224, 224), dtype=np.int8))
     stress("ivit_im2col_patch P=16", lambda: torch.empty(Bv * 196, 768, dtype=torch.int8, device="cuda"),
            lambda h, o: h.call("ivit_im2col_patch", P(imgv), Bv, 3, 224, 224, 16, P(o)), None)
