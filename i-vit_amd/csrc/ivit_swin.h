@@ -205,7 +205,9 @@ __global__ __launch_bounds__(256) void layernorm_tokenorder_kernel(const XT *__r
 // and runs its serial phase on 32 of 256 threads).  A thread keeps ONE channel group for the whole block — block size
 // (C / 8) x 16 — so its eight per-channel constants live in registers; the order-sensitive sums and the integer square
 // root run on 128 threads, one token each, on rows staged as fp32 with an odd pitch (conflict-free per-token walks).
-#define LNT8_ROWS 128
+#ifndef LNT8_ROWS
+#define LNT8_ROWS 96       // 37 KB of LDS per block = 4 blocks per CU (128 rows: 3 blocks, the requant pass 10 % slower; 64: no better)
+#endif
 template <int OUTM, int CC, typename XT>
 __global__ __launch_bounds__(CC / 8 * 16) void layernorm_tokenorder8_kernel(const XT *__restrict__ x, long long rows, float s,
                                                                             const float *__restrict__ bias_int,
