@@ -30,7 +30,11 @@ struct AttnArgs {
     int nc, t_count, dmin;
 };
 
-#define ATT_WAVES 7
+// wavefronts per workgroup.  8 = two workgroups per CU fill the 16 wave slots that 121 registers allow (round 4, after the prologue
+// changes: 52-54 us against 60-61 with 7, which had been the better choice in round 3; 6: slower)
+#ifndef ATT_WAVES
+#define ATT_WAVES 8
+#endif
 #ifndef ATT_PROBE          // timing probes only (results invalid): 1 first gather lane-linear, 2 second gather lane-linear with the
 #define ATT_PROBE 0        // first one dead, 4 second gather lane-linear with the first one kept alive, 8 no second gather
 #endif
