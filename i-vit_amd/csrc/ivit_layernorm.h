@@ -52,7 +52,10 @@ __device__ __forceinline__ float ln_dpp(float v) {
 // constants read from global memory instead of LDS, it still fails.  The library is now built with -packed-fp32-ops off
 // (i-vit_amd/_lib.py), which also covers the S = 4 forms and the token-order kernels whose ISA had packed fp32.
 // 32 rows per block whatever the split: the per-block staging of the channel constants (an fp64 division each) stays ~8 %
-#define LNR_THREADS(S) (128 * (S))
+#ifndef LNR_TB
+#define LNR_TB 128
+#endif
+#define LNR_THREADS(S) (LNR_TB * (S))
 // timing probes only (tools/ubench/ln_probe.hip): 1 = no output-pass arithmetic, 2 = no second sum, 4 = no Newton loop
 #ifndef LNR_ABLATE
 #define LNR_ABLATE 0
