@@ -71,7 +71,10 @@ __device__ __forceinline__ float ln_dpp(float v) {
 // register budget by values per lane (CC / 4S): <= 24 -> 8 waves per SIMD, <= 48 -> 5, <= 64 -> 4, more -> 3 (no scratch in any
 // instantiation the dispatcher uses)
 #define LNR_VPL(CC, S) ((CC) / (4 * (S)))
-#define LNR_MIN_WAVES(CC, S) (LNR_VPL(CC, S) <= 24 ? 8 : (LNR_VPL(CC, S) <= 48 ? 5 : (LNR_VPL(CC, S) <= 64 ? 4 : 3)))
+#ifndef LNR_W48
+#define LNR_W48 5
+#endif
+#define LNR_MIN_WAVES(CC, S) (LNR_VPL(CC, S) <= 24 ? 8 : (LNR_VPL(CC, S) <= 48 ? LNR_W48 : (LNR_VPL(CC, S) <= 64 ? 4 : 3)))
 template <int CC, int S>
 __global__ __launch_bounds__(LNR_THREADS(S), LNR_MIN_WAVES(CC, S)) void layernorm_reg_kernel(const int16_t *__restrict__ x, long long rows,
                                                                      long long row_stride, float s,
