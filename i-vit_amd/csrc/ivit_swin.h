@@ -353,8 +353,11 @@ struct WinAttnArgs {
 #define WA_PROBE 0         // 4 no global stores, 8 return after the operand loads
 #endif
 #define WA_FIXED(NW) ((NW) * (2048 + 64) + 4816 + 512 + 1024)
+#ifndef WA_MINW
+#define WA_MINW 6          // waves per SIMD the arithmetic kernel is compiled for (80 registers, three spilled dwords outside the score loops; 4: +3 %, 8: +18 %)
+#endif
 template <bool LUT>
-__global__ __launch_bounds__(LUT ? 512 : 256, 4) void window_attention_kernel(WinAttnArgs p) {
+__global__ __launch_bounds__(LUT ? 512 : 256, LUT ? 4 : WA_MINW) void window_attention_kernel(WinAttnArgs p) {
     constexpr int NW = LUT ? 8 : 4;
     extern __shared__ __attribute__((aligned(16))) char sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
