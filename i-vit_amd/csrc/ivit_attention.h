@@ -62,8 +62,11 @@ struct AttCfg {
 // test folds away; the generic form keeps ~70 loop-invariant lane masks alive and spills SGPRs in the hot loop.
 // LUT: shift-exp by table lookup (two LDS gathers per score instead of ~20 fp32 operations); the tables follow
 // the fixed LDS regions and are copied in once per workgroup.
+#ifndef ATT_MINW           // waves per SIMD the kernel is compiled for (probe; 1 = whatever the workgroup size implies)
+#define ATT_MINW 1
+#endif
 template <int NB, bool FAST, int TT = 0, bool LUT = false>
-__global__ __launch_bounds__(ATT_WAVES * 64) void attn_fused_kernel(AttnArgs p) {
+__global__ __launch_bounds__(ATT_WAVES * 64, ATT_MINW) void attn_fused_kernel(AttnArgs p) {
     using C = AttCfg<NB>;
     extern __shared__ __attribute__((aligned(16))) char dsmem[];
     char *sK = dsmem;
