@@ -101,6 +101,9 @@ const char *ivit_last_error(ivit_handle h) { return h ? h->err : "null handle"; 
 #ifndef IVIT_OPT_GEMM3_FMA
 #define IVIT_OPT_GEMM3_FMA (-1)         // -1: as the plan proves; 0 / 1: force the two-rounding / single-FMA requant (1 only where proven)
 #endif
+#ifndef G2_DBG
+#define G2_DBG 0
+#endif
 #ifndef IVIT_OPT_GEMM_BM
 #define IVIT_OPT_GEMM_BM 0              // 0: tile height by the occupancy estimate; 128 / 256: forced
 #endif
@@ -175,7 +178,7 @@ template <int EPI>
 static int launch_gemm2(ivit_handle h, GemmArgs &a) {
     a.tiles_n = (a.N + G2_BN - 1) / G2_BN;
     constexpr int force_bm = IVIT_OPT_GEMM_BM;
-    a.dbg = 0;
+    a.dbg = G2_DBG;                      // 0; timing probes: 1 main loop only, 2 no row stores, 3 no requant arithmetic
     // tile height: estimated time ~ ceil(tiles / resident slots) * rows per tile; 256-row tiles run
     // 2 per CU, 128-row tiles 3 per CU.  Ties go to the larger tile (better operand reuse).
     const long long t256 = (long long)((a.M + 255) / 256) * a.tiles_n, t128 = (long long)((a.M + 127) / 128) * a.tiles_n;

@@ -6,7 +6,7 @@ import ivit_amd as iv
 from ivit_amd import _lib
 P = lambda t: ctypes.c_void_p(t.data_ptr())
 H = _lib.Handle(0, torch.cuda.current_stream().cuda_stream)
-M = 50432
+M = int(os.environ.get("GB_M", "50432"))       # Swin-T b256: stage 0 GB_M=802816 (sq0, sp0), stage 1 GB_M=200704 (sq1, sp1, sf1)
 def timeit(fn, n=20):
     for _ in range(3): fn()
     torch.cuda.synchronize()
@@ -17,7 +17,8 @@ def timeit(fn, n=20):
     return a.elapsed_time(b) / n * 1e3
 rng = np.random.default_rng(0)
 SHAPES = [("qkv", 1152, 384), ("proj", 384, 384), ("fc1", 1536, 384), ("fc2", 384, 1536)]
-if os.environ.get("GB_SHAPES"): SHAPES = [x for x in SHAPES if x[0] in os.environ["GB_SHAPES"].split(",")]
+SWIN = [("sq0", 288, 96), ("sp0", 96, 96), ("sq1", 576, 192), ("sp1", 192, 192), ("sf1", 768, 192)]
+if os.environ.get("GB_SHAPES"): SHAPES = [x for x in SHAPES + SWIN if x[0] in os.environ["GB_SHAPES"].split(",")]
 for name, N, K in SHAPES:
     x = torch.from_numpy(rng.integers(-128, 128, (M, K), dtype=np.int8)).cuda()
     w = torch.from_numpy(rng.integers(-128, 128, (N, K), dtype=np.int8)).cuda()
