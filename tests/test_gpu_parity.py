@@ -1417,12 +1417,15 @@ def test_device_resize_center_crop_equals_oracle(H):
     assert np.array_equal(q, ref)
 
 
-@pytest.mark.parametrize("T,kind", [(197, "spread"), (197, "peaky"), (197, "saturated"), (577, "spread"), (577, "peaky"), (50, "saturated")])
+@pytest.mark.parametrize("T,kind", [(197, "spread"), (197, "peaky"), (197, "saturated"), (577, "spread"), (577, "peaky"), (50, "saturated"),
+                                    (1, "spread"), (64, "spread"), (65, "peaky"), (256, "spread"), (257, "saturated"), (640, "spread")])
 def test_fused_attention_core_vs_oracle(H, T, kind):
     """the fused attention kernels against the CPU ORACLE directly (not against the unfused HIP chain):
     q.k^T -> qact_attn1 -> Shiftmax(16) -> attn.v -> qact2 (vit_quant.py:70-83) at the token counts of the 224- and
-    384-pixel models, with score rows spread over the int8 range, peaky rows (one dominant key: the factor flips) and
-    saturated rows (many scores clamped at +-127/-128); both the arithmetic and the table-driven Shiftmax variants."""
+    384-pixel models and at the edges of the three kernel sizes (1, 64 | 65, 256 | 257, 640 keys: run-time token count, ragged
+    last query tile, every wavefront-to-tile assignment), with score rows spread over the int8 range, peaky rows (one dominant
+    key: the factor flips) and saturated rows (many scores clamped at +-127/-128); both the arithmetic and the table-driven
+    Shiftmax variants."""
     from oracle import oracle as orc
     rng = np.random.default_rng(T + len(kind))
     B, Hh, dh = 2, 2, 64
