@@ -177,6 +177,11 @@ def _cases(rng, variant=0):
     sl = (2.5e-4, 3.3e-4)[V]
     cs.append(("layernorm", [I(xl), Rl, C, sl, I(bias_int), I(sc), O(np.zeros((Rl, C), np.float32))]))
     cs.append(("layernorm_requant", [I(xl), Rl, C, C, sl, I(bias_int), I(sc), I(dl), O(np.zeros((Rl, C), np.int8))]))
+    # one channel with a multiplier far above the |z * c| < 2^31 bound: the block takes the v_rndne_f64 / saturating form of the
+    # 8-bit requant (ivit_layernorm.h) instead of the magic-number one
+    dl_wide = dl.copy()
+    dl_wide[3:4] = iv.freeze.dyadic(sc[3:4], np.float32(1e-13))
+    cs.append(("layernorm_requant", [I(xl), Rl, C, C, sl, I(bias_int), I(sc), I(dl_wide), O(np.zeros((Rl, C), np.int8))]))
     img = rng.integers(-128, 128, (2, 3, 32, 32), dtype=np.int8)
     cs.append(("im2col_patch", [I(img), 2, 3, 32, 32, 8, O(np.zeros((2 * 16, 3 * 64), np.int8))]))
     Te, De = ((17, 64), (10, 128))[V]
