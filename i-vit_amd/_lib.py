@@ -9,7 +9,7 @@ import subprocess
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 SO_PATH = os.environ.get("IVIT_LIB") or os.path.join(_CSRC, "libivit_hip.so")
-SOURCES = ["ivit_hip.hip", "ivit_device.h", "ivit_gemm.h", "ivit_elementwise.h", "ivit_layernorm.h", "ivit_attention.h", "ivit_gemm2.h", "ivit_gemm3.h", "ivit_swin.h", "ivit_mlp.h", "ivit_model.h"]
+SOURCES = ["ivit_hip.hip", "ivit_device.h", "ivit_gemm.h", "ivit_elementwise.h", "ivit_layernorm.h", "ivit_attention.h", "ivit_gemm2.h", "ivit_gemm3.h", "ivit_swin.h", "ivit_mlp.h", "ivit_mlp_rs.h", "ivit_model.h"]
 _THIS = os.path.abspath(__file__)
 # -packed-fp32-ops: no v_pk_{add,mul,fma}_f32 anywhere in the library.  Round 4 traced the sporadic one-LSB differences of
 # layernorm_reg_kernel<192, 1> beside QuantLinear GEMM workgroups to that instruction class (profiles/README.md round 4: the
@@ -193,7 +193,7 @@ SIGNATURES = {
     "ivit_im2col_patch": [_P, _P, _I, _I, _I, _I, _I, _P],
     "ivit_embed_finish": [_P, _P, _P, _P, Dyadic, Dyadic, _P, _I, _I, _I],
 }
-OTHER_SYMBOLS = ["ivit_version", "ivit_status_string", "ivit_last_error", "ivit_linear_plan_destroy", "ivit_mlp_plan_destroy", "ivit_linear_plan_query", "ivit_debug_plan_scratch"]
+OTHER_SYMBOLS = ["ivit_version", "ivit_status_string", "ivit_last_error", "ivit_linear_plan_destroy", "ivit_mlp_plan_destroy", "ivit_linear_plan_query", "ivit_debug_plan_scratch", "ivit_mlp_plan_select"]
 
 _lib = None
 
@@ -222,6 +222,10 @@ def load():
     lib.ivit_linear_plan_query.restype = ctypes.c_int
     lib.ivit_debug_plan_scratch.argtypes = [_P, _P, _I]
     lib.ivit_debug_plan_scratch.restype = ctypes.c_int
+    lib.ivit_mlp_plan_select.argtypes = [_P, _I]
+    lib.ivit_mlp_plan_select.restype = ctypes.c_int
+    lib.ivit_mlp_plan_destroy.argtypes = [_P]
+    lib.ivit_mlp_plan_destroy.restype = ctypes.c_int
     _lib = lib
     return lib
 

@@ -17,6 +17,7 @@
 #include "ivit_gemm3.h"
 #include "ivit_swin.h"
 #include "ivit_mlp.h"
+#include "ivit_mlp_rs.h"
 
 struct ivit_ctx {
     int device;
@@ -590,10 +591,15 @@ int ivit_linear_i8_qkv_planned(ivit_handle h, ivit_linear_plan pl, const int8_t 
 }  // extern "C"
 
 // ---- fused Mlp (+ residual QuantAct) for D = 384, hidden = 1536 (ivit_mlp.h)
+#ifndef IVIT_OPT_MLP_RS
+#define IVIT_OPT_MLP_RS 1               // A/B builds: 0 = the shape-based default never picks the role-split kernel
+#endif
 struct ivit_mlp_plan_s {
     ivit_linear_plan fc1, fc2;      // borrowed: must outlive this plan
     v4i *w1f, *w2f;                 // fragment-ordered copies of the two weight matrices (one allocation)
+    v4i *w1r, *w2r;                 // the same in the role-split kernel's order (ivit_mlp_rs.h), same allocation
     int fma;                        // both layers: one fused rounding == the reference's two
+    int kernel;                     // 0 = by shape, 1 = lock-step (mlp384_kernel), 2 = role-split (mlp384rs_kernel): ivit_mlp_plan_select
     int device;
 };
 
@@ -612,9 +618,11 @@ int ivit_mlp_plan_create(ivit_handle h, ivit_linear_plan fc1, ivit_linear_plan f
     }
     const size_t wbytes = (size_t)MLP_C * MLP_HD;
     char *dev = nullptr;
-    if (hipMalloc((void **)&dev, 2 * wbytes) != hipSuccess) { snprintf(h->err, sizeof(h->err), "%s: hipMalloc failed", __func__); return IVIT_ERR_HIP; }
+    if (hipMalloc((void **)&dev, 4 * wbytes) != hipSuccess) { snprintf(h->err, sizeof(h->err), "%s: hipMalloc failed", __func__); return IVIT_ERR_HIP; }
     mlp_swizzle_kernel<<<256, 256, 0, h->stream>>>(fc1->w, MLP_HD, MLP_C, (v4i *)dev);
     mlp_swizzle_kernel<<<256, 256, 0, h->stream>>>(fc2->w, MLP_C, MLP_HD, (v4i *)(dev + wbytes));
+    rs_swizzle_w1_kernel<<<144, 256, 0, h->stream>>>(fc1->w, (v4i *)(dev + 2 * wbytes));
+    rs_swizzle_w2_kernel<<<144, 256, 0, h->stream>>>(fc2->w, (v4i *)(dev + 3 * wbytes));
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) {     // plan creation is a build-time call
         (void)hipFree(dev);
         snprintf(h->err, sizeof(h->err), "%s: HIP error", __func__);
@@ -623,11 +631,15 @@ int ivit_mlp_plan_create(ivit_handle h, ivit_linear_plan fc1, ivit_linear_plan f
     ivit_mlp_plan_s *p = new (std::nothrow) ivit_mlp_plan_s();
     if (!p) { (void)hipFree(dev); return IVIT_ERR_HIP; }
     p->fc1 = fc1; p->fc2 = fc2; p->w1f = (v4i *)dev; p->w2f = (v4i *)(dev + wbytes);
+    p->w1r = (v4i *)(dev + 2 * wbytes); p->w2r = (v4i *)(dev + 3 * wbytes);
     p->fma = fc1->single_fma_ok && fc2->single_fma_ok;
+    p->kernel = 0;
     p->device = h->device;
-    {   // the dynamic-LDS attribute of the kernel this plan will launch: once, here
+    {   // the dynamic-LDS attributes of the kernels this plan will launch: once, here
         const void *fn = p->fma ? (const void *)mlp384_kernel<true> : (const void *)mlp384_kernel<false>;
+        const void *fr = p->fma ? (const void *)mlp384rs_kernel<true> : (const void *)mlp384rs_kernel<false>;
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_SMEM);
+        if (e == hipSuccess) e = hipFuncSetAttribute(fr, hipFuncAttributeMaxDynamicSharedMemorySize, RS_SMEM);
         if (e != hipSuccess) {
             snprintf(h->err, sizeof(h->err), "%s: attr: %s", __func__, hipGetErrorString(e));
             (void)hipFree(dev);
@@ -636,6 +648,12 @@ int ivit_mlp_plan_create(ivit_handle h, ivit_linear_plan fc1, ivit_linear_plan f
         }
     }
     *out = p;
+    return IVIT_OK;
+}
+
+int ivit_mlp_plan_select(ivit_mlp_plan p, int kernel) {
+    if (!p || kernel < 0 || kernel > 2) return IVIT_ERR_INVALID;
+    p->kernel = kernel;
     return IVIT_OK;
 }
 
@@ -667,7 +685,15 @@ int ivit_mlp_fused_planned(ivit_handle h, ivit_mlp_plan p, const int8_t *x, cons
     const unsigned grid = (unsigned)(nunits < h->num_cu ? nunits : h->num_cu);
     const long long rounds_fixed = (nunits + grid - 1) / grid, rounds_bal = (ntiles + (long long)MLP_TT * grid - 1) / ((long long)MLP_TT * grid);
     a.balanced = rounds_bal < rounds_fixed;
-    if (p->fma) mlp384_kernel<true><<<grid, MLP_THREADS, MLP_SMEM, h->stream>>>(a);
+    // two kernels, the same integers.  The role-split one (producer waves on fc1 of unit u + 1 beside consumer waves on
+    // ShiftGELU / fc2 / epilogue of unit u) needs a second unit per workgroup to overlap anything: with one unit per CU it only
+    // ties with the lock-step kernel (45.0 vs 44.6 us at M = 20480), from two units on it wins (profiles/README.md, round 5)
+    const bool role_split = p->kernel == 2 || (p->kernel == 0 && IVIT_OPT_MLP_RS && nunits > (long long)grid);
+    if (role_split) {
+        a.w1f = p->w1r; a.w2f = p->w2r;
+        if (p->fma) mlp384rs_kernel<true><<<grid, RS_THREADS, RS_SMEM, h->stream>>>(a);
+        else mlp384rs_kernel<false><<<grid, RS_THREADS, RS_SMEM, h->stream>>>(a);
+    } else if (p->fma) mlp384_kernel<true><<<grid, MLP_THREADS, MLP_SMEM, h->stream>>>(a);
     else mlp384_kernel<false><<<grid, MLP_THREADS, MLP_SMEM, h->stream>>>(a);
     LAUNCH_CHECK(h);
     return IVIT_OK;

@@ -418,6 +418,10 @@ int ivit_mlp_fused(ivit_handle h, const int8_t *x, const int8_t *w1, const int32
 typedef struct ivit_mlp_plan_s *ivit_mlp_plan;
 int ivit_mlp_plan_create(ivit_handle h, ivit_linear_plan fc1, ivit_linear_plan fc2, ivit_mlp_plan *out);
 int ivit_mlp_plan_destroy(ivit_mlp_plan p);
+/* Tuning / test switch: which of the plan's two kernels ivit_mlp_fused_planned launches.  0 = by shape (the default:
+ * the role-split kernel of csrc/ivit_mlp_rs.h from two 80-token units per CU on, the lock-step kernel of csrc/ivit_mlp.h
+ * below that), 1 = lock-step, 2 = role-split.  Both compute the same integers (layers_quant.py:144-153).            */
+int ivit_mlp_plan_select(ivit_mlp_plan p, int kernel);
 int ivit_mlp_fused_planned(ivit_handle h, ivit_mlp_plan p, const int8_t *x, const int8_t *gelu_table,
                            ivit_dyadic dy_main, ivit_dyadic dy_res, const int16_t *residual, int16_t *out,
                            int64_t M);

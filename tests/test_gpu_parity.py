@@ -576,12 +576,16 @@ def test_mlp_fused_planned_vs_oracle_production_geometry(M):
     assert twin.ivit_cpu_linear_plan_create(None, hp(w1), hp(b1), hp(d1), Hd, C, ctypes.byref(c1)) == 0
     assert twin.ivit_cpu_linear_plan_create(None, hp(w2), hp(b2), hp(d2), C, Hd, ctypes.byref(c2)) == 0
     assert twin.ivit_cpu_mlp_plan_create(None, c1, c2, ctypes.byref(cm)) == 0
-    og = torch.full((M, C), 0x5555, dtype=torch.int16, device="cuda")
-    H.call("ivit_mlp_fused_planned", gm, _P(d["x"].data_ptr()), _P(tabd.data_ptr()), dyv(dm), dyv(dr), _P(d["res"].data_ptr()), _P(og.data_ptr()), M)
     oc = np.zeros((M, C), np.int16)
     assert twin.ivit_cpu_mlp_fused_planned(None, cm, hp(x), hp(tab), dyv(dm), dyv(dr), hp(res), hp(oc), M) == 0
-    got = og.cpu().numpy()
-    assert np.array_equal(got, oc), int((got != oc).sum())
+    # round 5: the plan owns two kernels (lock-step ivit_mlp.h, role-split ivit_mlp_rs.h); 0 = the shape-based default
+    for kernel in (0, 1, 2):
+        assert H.lib.ivit_mlp_plan_select(gm, kernel) == 0
+        og = torch.full((M, C), 0x5555, dtype=torch.int16, device="cuda")
+        H.call("ivit_mlp_fused_planned", gm, _P(d["x"].data_ptr()), _P(tabd.data_ptr()), dyv(dm), dyv(dr), _P(d["res"].data_ptr()), _P(og.data_ptr()), M)
+        got = og.cpu().numpy()
+        assert np.array_equal(got, oc), (kernel, int((got != oc).sum()))
+    assert H.lib.ivit_mlp_plan_select(gm, 3) == 1 and H.lib.ivit_mlp_plan_select(None, 0) == 1
     H.lib.ivit_mlp_plan_destroy(gm); twin.ivit_cpu_mlp_plan_destroy(cm)
     for pl in (g1, g2):
         H.lib.ivit_linear_plan_destroy(pl)
@@ -805,10 +809,12 @@ def test_mlp_fused_planned_equals_unfused_chain(H, M):
         H.call("ivit_linear_i8_requant_residual_planned", p2, P(g8), dyv(dm), dyv(dr), P(res), P(ref), M)
         hh = h8.cpu().numpy().astype(np.int32)
         assert hh.max() == 127 and hh.min() == -128          # the hidden tensor saturates on both sides
-        for _ in range(3):
+        for rep in range(6):                                  # both kernels of the plan (ivit_mlp_plan_select), repeated launches
+            assert H.lib.ivit_mlp_plan_select(mp, 1 + rep % 2) == 0
             out = torch.full((M, C), -7, dtype=torch.int16, device="cuda")
             H.call("ivit_mlp_fused_planned", mp, P(x), P(tab), dyv(dm), dyv(dr), P(res), P(out), M)
-            assert np.array_equal(out.cpu().numpy(), ref.cpu().numpy())
+            assert np.array_equal(out.cpu().numpy(), ref.cpu().numpy()), rep
+        assert H.lib.ivit_mlp_plan_select(mp, 0) == 0
         # multipliers outside the fast residual range are refused, not mis-computed
         big = _lib.Dyadic(1024.0, 1.0)
         assert H.lib.ivit_mlp_fused_planned(H.h, mp, P(x), P(tab), big, dyv(dr), P(res), P(out), M) == 3
