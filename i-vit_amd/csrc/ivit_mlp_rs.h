@@ -59,18 +59,12 @@
 #endif
 #ifndef RS_ABL
 #define RS_ABL 0                                 // probe builds, timing only (results invalid): 1 no ShiftGELU body, 2 no epilogue arithmetic,
-#endif                                           // 4 no producer requant arithmetic, 8 no consumer MFMAs, 16 no producer MFMAs
-#ifndef RS_PRIO
-#define RS_PRIO 0                                // s_setprio of the consumer waves
-#endif
+#endif                                           // 4 no producer requant arithmetic
 #ifndef RS_HELP
 #define RS_HELP 1                                // the consumers multiply rounds 6..11 of the FIRST unit's fc1 (they have nothing else to do yet)
 #endif
 #ifndef RS_GSPLIT
 #define RS_GSPLIT 1                              // ShiftGELU of a unit on all sixteen half-waves (0: the consumers' eight)
-#endif
-#ifndef RS_YIELD
-#define RS_YIELD 0                               // producers do not start a round while a consumer is inside fc2's K loop
 #endif
 #ifndef RS_DBG_ROLE
 #define RS_DBG_ROLE 3                            // probe builds: 1 = producers only, 2 = consumers only (resource usage per role)
@@ -125,27 +119,6 @@ __device__ __forceinline__ void rs_wait(unsigned flag_addr, unsigned target) {
                  "s_trap 2\n"
                  ".Lrsd%=:"
                  : "=&v"(v), "=&s"(cnt), "=&s"(tmp) : "v"(flag_addr), "s"(target) : "memory", "scc");
-}
-
-// spin while the two counters at flag_addr differ (consumers that entered fc2's K loop and consumers that left it)
-__device__ __forceinline__ void rs_wait_equal(unsigned flag_addr) {
-    unsigned v0, v1, a, b, cnt;
-    asm volatile("s_mov_b32 %4, 0\n"
-                 ".Lrse%=:\n\t"
-                 "ds_read_b32 %0, %5\n\t"
-                 "ds_read_b32 %1, %5 offset:4\n\t"
-                 "s_waitcnt lgkmcnt(0)\n\t"
-                 "v_readfirstlane_b32 %2, %0\n\t"
-                 "v_readfirstlane_b32 %3, %1\n\t"
-                 "s_cmp_eq_u32 %2, %3\n\t"
-                 "s_cbranch_scc1 .Lrsf%=\n\t"
-                 "s_sleep 2\n\t"
-                 "s_add_u32 %4, %4, 1\n\t"
-                 "s_cmp_lt_u32 %4, 0x100000\n\t"
-                 "s_cbranch_scc1 .Lrse%=\n\t"
-                 "s_trap 2\n"
-                 ".Lrsf%=:"
-                 : "=&v"(v0), "=&v"(v1), "=&s"(a), "=&s"(b), "=&s"(cnt) : "v"(flag_addr) : "memory", "scc");
 }
 
 template <bool FMA>
@@ -260,7 +233,6 @@ __global__ __launch_bounds__(RS_THREADS, 2) void mlp384rs_kernel(MlpArgs p) {
 #pragma unroll
             for (int rr = 0; rr < RS_HD; ++rr) {
                 const int r = it * RS_HD + rr, chb = 128 * r + 32 * pw + 16 * kh;
-                if (RS_YIELD) rs_wait_equal(fl + 4 * 16);      // probe: no producer K loop beside the consumers' fc2 K loop
                 v16i acc[NT];
                 v2d cq[8];                             // this round's multipliers: requested four k-steps before the requant
 #pragma unroll
@@ -276,11 +248,7 @@ __global__ __launch_bounds__(RS_THREADS, 2) void mlp384rs_kernel(MlpArgs p) {
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
-                        if (RS_ABL & 16) {
-                            if (ks == 0) acc[t] = bias;
-                            acc[t][0] ^= wf[s % RS_WR][0] ^ bf[ks & 1][t][0];
-                        } else
-                            acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[s % RS_WR], bf[ks & 1][t], ks == 0 ? bias : acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[s % RS_WR], bf[ks & 1][t], ks == 0 ? bias : acc[t], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (it > it0) flush(rr, r - RS_HD);
@@ -404,7 +372,6 @@ __global__ __launch_bounds__(RS_THREADS, 2) void mlp384rs_kernel(MlpArgs p) {
 
     if (wave < 4) {
         // =========================================================================================== producers
-        if (RS_PRIO & 8) __builtin_amdgcn_s_setprio(3);                   // probe: static priority of the producers
         if (wave == 0) {
             a_dma(unit_tile0(0), unit_ntt(0));
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -430,7 +397,6 @@ __global__ __launch_bounds__(RS_THREADS, 2) void mlp384rs_kernel(MlpArgs p) {
     } else {
         // =========================================================================================== consumers
         const int j = wave - 4;
-        if (RS_PRIO & 3) __builtin_amdgcn_s_setprio(RS_PRIO & 3);      // probe: static priority of the consumers
         if (RS_HELP && (RS_DBG_ROLE & 1)) {
             // the first unit's fc1, second half of the rounds: nothing else for a consumer to do until a hidden tile exists
             static_assert(!RS_HELP || 12 / RS_HD == 2, "the first unit is split by iterations");
@@ -470,8 +436,6 @@ __global__ __launch_bounds__(RS_THREADS, 2) void mlp384rs_kernel(MlpArgs p) {
             stamp(u, 4);
             // ---- fc2: output channels 96 j + 32 ct + 16 kh + v of token t * 32 + tok in acc[ct][t][v]
             v16i acc[3][NT];
-            if (RS_PRIO & 4) __builtin_amdgcn_s_setprio(3);               // probe: consumers first while they multiply
-            if (RS_YIELD) rs_signal(fl + 4 * 16);
             {
                 v16i bias[3];
 #pragma unroll
@@ -493,17 +457,11 @@ __global__ __launch_bounds__(RS_THREADS, 2) void mlp384rs_kernel(MlpArgs p) {
                     for (int ct = 0; ct < 3; ++ct)
 #pragma unroll
                         for (int t = 0; t < NT; ++t)
-                            if (RS_ABL & 8) {
-                                if (ks == 0) acc[ct][t] = bias[ct];
-                                acc[ct][t][0] ^= wf[ks % (RS_WD2 + 1)][ct][0] ^ bf[ks & 1][t][0];
-                            } else
-                                acc[ct][t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[ks % (RS_WD2 + 1)][ct], bf[ks & 1][t],
-                                                                                    ks == 0 ? bias[ct] : acc[ct][t], 0, 0, 0);
+                            acc[ct][t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[ks % (RS_WD2 + 1)][ct], bf[ks & 1][t],
+                                                                                ks == 0 ? bias[ct] : acc[ct][t], 0, 0, 0);
                 }
             }
             stamp(u, 5);
-            if (RS_YIELD) rs_signal(fl + 4 * 17);
-            if (RS_PRIO & 4) __builtin_amdgcn_s_setprio(0);
             // ---- qact2 (16 bit) + qact4 with the identity branch: 16 consecutive channels of a token per lane.  The identity rows
             // of tile n + 2 and the multipliers of the next channel tile are requested while tile n is requantised
             const long long tok0 = tile0 * 16;
