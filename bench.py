@@ -279,6 +279,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def all_ranks_exit_unless(ok_here, msg):
+        """ok_here is rank 0's verdict (other ranks pass True): every rank learns it and leaves together."""
+        on = device if os.environ.get("IVIT_DIST_BACKEND", "nccl") == "nccl" else "cpu"
+        flag = torch.tensor([1 if ok_here else 0], dtype=torch.int32, device=on)
+        if world > 1:
+            dist.broadcast(flag, src=0)
+        if int(flag.item()) == 0:
+            if world > 1:
+                dist.destroy_process_group()
+            raise SystemExit(msg)
+
     if args.graph:
         step = eng.capture(imgs, streams)
     else:
@@ -291,9 +302,9 @@ def main():
         ref_all = eng.forward(imgs, nslices=1).clone()
         ok_all = all(bool(torch.equal(step(), ref_all)) for _ in range(5))
         del ref_all
-        if not ok_all:
-            # a wrong image is not a benchmark result: no JSON line, non-zero exit
-            raise SystemExit("bench.py: the sliced / graph forward differs from the unsliced forward in at least one image; nothing timed")
+    # a wrong image is not a benchmark result: no JSON line, non-zero exit — on EVERY rank (rank 0 alone leaving would
+    # strand the others in the next barrier until the RCCL timeout)
+    all_ranks_exit_unless(ok_all is not False, "bench.py: the sliced / graph forward differs from the unsliced forward in at least one image; nothing timed")
     for _ in range(args.warmup):
         step()
     rep_dt = []
@@ -317,8 +328,7 @@ def main():
     ok = None
     if rank == 0 and batch >= gb:
         ok = bool(np.array_equal(step()[:gb].cpu().numpy(), g["logits_int"]))
-        if not ok:
-            raise SystemExit("bench.py: logits of the golden prefix differ from the reference's; nothing reported")
+    all_ranks_exit_unless(ok is not False, "bench.py: logits of the golden prefix differ from the reference's; nothing reported")
 
     # per-operator HIP-event timing (separate instrumented steps, one stream, one C-ABI call per operator)
     per = {}

@@ -81,6 +81,11 @@ __global__ __launch_bounds__(ATT_WAVES * 64, ATT_MINW) void attn_fused_kernel(At
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
     const int T = TT ? TT : p.T;
+    // The exp-table gathers below address the table as the LITERAL C::SMEM + offset (an integer-built LDS address keeps the
+    // constant in the instruction's offset field; through the pointer every gather pays a v_add of the link-time base).  That
+    // is only right while this kernel's dynamic LDS block starts at LDS address 0 — true as long as it has no static
+    // __shared__ — so a layout change fails loudly here instead of reading the wrong table.
+    if (LUT && (unsigned)(size_t)((__attribute__((address_space(3))) char *)dsmem) != 0u) __builtin_trap();
     const int8_t *qg = p.q + (long long)bh * T * 64;
     const int8_t *kg = p.k + (long long)bh * T * 64;
     const int8_t *vg = p.vt + (long long)bh * 64 * p.ldv;

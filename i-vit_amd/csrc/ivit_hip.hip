@@ -47,7 +47,7 @@ struct ivit_device_guard {
 
 extern "C" {
 
-int ivit_version(void) { return 100; }
+int ivit_version(void) { return IVIT_VERSION; }
 
 const char *ivit_status_string(int s) {
     switch (s) {

@@ -253,10 +253,10 @@ class QuantAct(nn.Module):
         then its scale (quant_utils.py:51-69).  Range statistics are torch reductions on the device;
         they run in calibration only, never on the frozen inference path."""
         ref_val = getattr(x, "_calib_fp32", None)      # IntGELU in calibration mode: the reference's own fp32 tensor
-        if s_pre is None:
-            X = x.float()
-        elif ref_val is not None and identity is None:
+        if ref_val is not None and identity is None:     # both conventions: the integer pair and the fake-quant tensor
             X = ref_val
+        elif s_pre is None:
+            X = x.float()
         else:
             X = x.float() * torch.as_tensor(_f32(s_pre), device=x.device)
             if identity is not None:

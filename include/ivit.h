@@ -48,6 +48,11 @@ enum {
     IVIT_ERR_NO_DEVICE = 4
 };
 
+/* 100 * major + minor.  101 (round 5): ivit_mlp_plan_select; ivit_swin_block / ivit_vit_block carry the optional Shiftmax-table
+ * fields exp_* at their END (added in 100 without a bump: a caller compiled against an older layout must be rebuilt).
+ * Parameter structs are read field by field: ZERO-INITIALISE them (memset / = {0}) before filling — exp_aq == NULL (and
+ * exp_nc == exp_tcount == exp_dmin == 0) selects the arithmetic Shiftmax, anything else is taken as device pointers.        */
+#define IVIT_VERSION 101
 int ivit_version(void);
 const char *ivit_status_string(int status);
 
@@ -324,7 +329,7 @@ typedef struct ivit_swin_block {
     ivit_lin_params fc1; float s_gelu; ivit_dyadic dy_gelu; ivit_lin_params fc2;   /* mlp (layers_quant.py:144-153) */
     ivit_dyadic res2_main, res2_res;                       /* qact4 with identity (:296)                        */
     const uint16_t *exp_aq; const float *exp_t; const uint8_t *exp_cls;   /* optional Shiftmax tables for s_softmax (NULL: arithmetic) */
-    int exp_nc, exp_tcount, exp_dmin;
+    int exp_nc, exp_tcount, exp_dmin;                      /* zero-initialise the struct: garbage here is read as pointers */
 } ivit_swin_block;
 
 typedef struct ivit_swin_merge {                           /* PatchMerging: norm -> qact1 -> reduction -> qact2 */

@@ -661,6 +661,25 @@ def test_calibration_reproduces_reference_scales(fname):
         assert np.array_equal(acc.cpu().numpy(), g["logits_int"])
 
 
+def test_calibration_through_the_fake_quant_surface():
+    """the same calibration with the model on the reference's fp32 fake-quant tensors (VisionTransformer.fake_quant):
+    the QuantAct behind ShiftGELU must track the reference's own fp32 value there too (IntGELU's `_calib_fp32` rides on the
+    fake-quant tensor), so every scale of the micro-ViT fixture is bit-equal to the reference's on this path as well."""
+    g = load_golden("micro_vit_b2.npz")
+    cfg = iv.CONFIGS[str(g["cfg_name"])]
+    m = iv.VisionTransformer(img_size=cfg.img_size, patch_size=cfg.patch_size, num_classes=cfg.num_classes,
+                             embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads, mlp_ratio=4)
+    m.load_float_weights(iv.make_vit_weights(cfg, int(g["seed"])))
+    m.fake_quant = True
+    with torch.no_grad():
+        m(dev(iv.make_calibration_batch(cfg, CALIB_BATCH["micro_vit_b2.npz"])))
+    iv.freeze_model(m)
+    ref = golden_scales(g)
+    got = {k: np.float32(mod.act_scaling_factor.reshape(-1)[0].item()) for k, mod in m.named_modules() if type(mod) is iv.QuantAct}
+    diff = [k for k in ref if ref[k] > 0 and k in got and got[k] != ref[k]]
+    assert not diff, diff[:4]
+
+
 def test_imported_reference_state_dict_runs_to_golden_logits():
     """checkpoint importer: the reference's post-forward state dict -> this build's
     operator chain and fused engine -> the reference's logits."""
