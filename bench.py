@@ -118,7 +118,7 @@ def pmc_traffic_per_kernel(batch, T, D, Hd):
     except Exception:
         return None
     M = batch * T
-    alg = {"mlp384_kernel": M * D + 2 * 2 * M * D + 2 * D * Hd,                 # x, identity in, out, both weight matrices
+    alg = {"mlp384": M * D + 2 * 2 * M * D + 2 * D * Hd,                        # mlp384_kernel / mlp384rs_kernel: x, identity in, out, both weight matrices
            "gemm_as_kernel<5": M * D + 3 * M * D + 3 * D * D,                   # qkv: x, q / k / v^T, weights
            "gemm_glds_kernel<3": M * D + 2 * 2 * M * D + D * D}                 # proj: ctx, identity in, out, weights
     out = {}
@@ -252,7 +252,7 @@ def main():
 
     family, gname, cfg_batch, which = WORKLOADS[args.model]
     batch = args.batch or cfg_batch
-    streams = args.streams or {"deit_tiny": 1, "deit_small": 2, "deit_base": 2, "swin_tiny": 4, "vit_base_384": 2}[args.model]
+    streams = args.streams or {"deit_tiny": 1, "deit_small": 2, "deit_base": 2, "swin_tiny": 2, "vit_base_384": 2}[args.model]   # Swin-T: 2 since round 5 (the role-split Mlp of stage 2 needs two units per CU: 51.0 k vs 49.5 k img/s with 4)
     streams = max(1, min(streams, batch))
     cfg = iv.CONFIGS[args.model] if family == "vit" else iv.SWIN_CONFIGS[args.model]
     g = np.load(os.path.join(ROOT, "tests", "golden", gname))
@@ -387,7 +387,7 @@ def main():
         hbm_ops = {k: v for k, v in hbm_ops.items() if v is not None}
         roofline = {
             "kernel": "QuantLinear GEMM class: gemm_as_kernel / gemm_ps_kernel / gemm_glds_kernel (patch-embed, qkv, proj, head; fused "
-                      "requant epilogues) and mlp384_kernel (fc1 + ShiftGELU + fc2 + residual QuantAct in one launch where D = 384; its "
+                      "requant epilogues) and mlp384rs_kernel / mlp384_kernel (fc1 + ShiftGELU + fc2 + residual QuantAct in one launch where D = 384; its "
                       "ShiftGELU table pass is inside the time the OPs are divided by)",
             "bound": "mfma", "achieved": None if achieved is None else round(achieved, 1),
             "peak": INT8_PEAK_TOPS, "unit": "TOP/s",

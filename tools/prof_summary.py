@@ -67,7 +67,7 @@ if pm:
 
 # ---- HBM traffic per QuantLinear GEMM launch -> pmc_traffic.json (feeds bench.py roofline.traffic)
 import json
-gemm = {k: v for k, v in pm.items() if k.startswith("gemm_") or k.startswith("mlp384_kernel")}
+gemm = {k: v for k, v in pm.items() if k.startswith("gemm_") or k.startswith("mlp384")}
 if gemm and all("FETCH_SIZE" in v and "WRITE_SIZE" in v for v in gemm.values()):
     per, tot_b, tot_n = {}, 0.0, 0
     for k, v in gemm.items():
@@ -81,4 +81,4 @@ if gemm and all("FETCH_SIZE" in v and "WRITE_SIZE" in v for v in gemm.values()):
           "command": "python bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile-steps 0 --streams 1 --graph 0",
           "per_kernel": per, "avg_bytes_per_launch": tot_b / tot_n}
     json.dump(js, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
-    print("\npmc_traffic.json: avg HBM bytes per GEMM-class launch (gemm_* and mlp384_kernel) %.1f MB" % (tot_b / tot_n / 1e6))
+    print("\npmc_traffic.json: avg HBM bytes per GEMM-class launch (gemm_*, mlp384_kernel, mlp384rs_kernel) %.1f MB" % (tot_b / tot_n / 1e6))
