@@ -15,6 +15,7 @@
 #include "ivit_attention.h"
 #include "ivit_gemm2.h"
 #include "ivit_gemm3.h"
+#include "ivit_gemm_wreg.h"
 #include "ivit_swin.h"
 #include "ivit_mlp.h"
 #include "ivit_mlp_rs.h"
@@ -197,6 +198,40 @@ static int launch_gemm2(ivit_handle h, GemmArgs &a) {
 }
 static inline bool use_gemm2(const GemmArgs &a) { return (a.K % 32) == 0 && a.K >= 64 && (a.lda % 16) == 0 && (a.ldb % 16) == 0; }
 
+// short-K streaming kernel (ivit_gemm_wreg.h): K = 96 / 128 / 192 with whole 32-channel tiles in groups of 3 or 2, plain row-major
+// operands, enough rows to keep every CU busy
+#ifndef IVIT_OPT_GEMM_WREG
+#define IVIT_OPT_GEMM_WREG 1
+#endif
+static inline int wreg_nct(const GemmArgs &a) {
+    if (!IVIT_OPT_GEMM_WREG || a.K % 32 || !(a.K == 96 || a.K == 128 || a.K == 192) || a.N % 32 || a.lda != a.K || a.ldb != a.K ||
+        a.ldc != a.N || a.M < 8192 || a.inner != 1)
+        return 0;
+    const int nt = a.N / 32;
+    return nt % 3 == 0 ? 3 : (nt % 2 == 0 ? 2 : 0);
+}
+template <int EPI, int KS, int NCT>
+static int launch_wreg_k(ivit_handle h, const GemmArgs &a) {
+    const int ncg = a.N / (32 * NCT);
+    static int wpc = 0;                              // resident workgroups per CU of this instantiation (registers, LDS): once
+    if (!wpc) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_wreg_kernel<EPI, KS, NCT>, GW_THREADS, 0) != hipSuccess || n < 1) n = 1;
+        wpc = n;
+    }
+    int per = (h->num_cu * wpc) / (8 * ncg);
+    if (per < 1) per = 1;
+    gemm_wreg_kernel<EPI, KS, NCT><<<dim3((unsigned)(8 * ncg * per)), GW_THREADS, 0, h->stream>>>(a);
+    LAUNCH_CHECK(h);
+    return IVIT_OK;
+}
+template <int EPI>
+static int launch_wreg(ivit_handle h, const GemmArgs &a, int nct) {
+    const int ks = a.K / 32;
+    if (nct == 3) return ks == 3 ? launch_wreg_k<EPI, 3, 3>(h, a) : (ks == 4 ? launch_wreg_k<EPI, 4, 3>(h, a) : launch_wreg_k<EPI, 6, 3>(h, a));
+    return ks == 3 ? launch_wreg_k<EPI, 3, 2>(h, a) : (ks == 4 ? launch_wreg_k<EPI, 4, 2>(h, a) : launch_wreg_k<EPI, 6, 2>(h, a));
+}
+
 static GemmArgs linear_args(const int8_t *x, const int8_t *w, const int32_t *bias, int M, int N, int K) {
     GemmArgs a;
     memset(&a, 0, sizeof(a));
@@ -226,6 +261,7 @@ int ivit_linear_i8_requant(ivit_handle h, const int8_t *x, const int8_t *w, cons
     REQUIRE(h, bits == 8 || bits == 16, "bits must be 8 or 16");
     GemmArgs a = linear_args(x, w, bias, M, N, K);
     a.out = out; a.dy_ch = dy_ch;
+    if (const int nct = wreg_nct(a)) return bits == 8 ? launch_wreg<EPI_RQ8_CH>(h, a, nct) : launch_wreg<EPI_RQ16_CH>(h, a, nct);
     if (use_gemm2(a)) return bits == 8 ? launch_gemm2<EPI_RQ8_CH>(h, a) : launch_gemm2<EPI_RQ16_CH>(h, a);
     return bits == 8 ? launch_gemm<false, EPI_RQ8_CH>(h, a, 1) : launch_gemm<false, EPI_RQ16_CH>(h, a, 1);
 }
@@ -238,6 +274,7 @@ int ivit_linear_i8_requant_residual(ivit_handle h, const int8_t *x, const int8_t
     REQUIRE(h, (K % 16) == 0, "K must be a multiple of 16");
     GemmArgs a = linear_args(x, w, bias, M, N, K);
     a.out = out; a.dy_ch = dy_ch; a.dy_main = dy_main; a.dy_res = dy_res; a.residual = residual;
+    if (const int nct = wreg_nct(a)) return launch_wreg<EPI_RQ16_CH_RES>(h, a, nct);
     if (use_gemm2(a)) return launch_gemm2<EPI_RQ16_CH_RES>(h, a);
     return launch_gemm<false, EPI_RQ16_CH_RES>(h, a, 1);
 }

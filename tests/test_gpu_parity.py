@@ -208,7 +208,11 @@ def test_linear_i8_vs_numpy(H, M, N, K):
 
 @pytest.mark.parametrize("M,N,K", [(256, 128, 64), (788, 384, 384), (300, 1152, 192), (197, 1000, 384),
                                    (50, 10, 64), (513, 136, 1536), (394, 384, 48), (300, 288, 96), (257, 96, 96),
-                                   (130, 384, 160), (640, 96, 352)])
+                                   (130, 384, 160), (640, 96, 352),
+                                   # round 5: M >= 8192 with K = 96 / 128 / 192 runs the weights-in-registers streaming kernel
+                                   # (ivit_gemm_wreg.h): channel groups of 3 and of 2 tiles, ragged last row tile
+                                   (8192 + 77, 288, 96), (8300, 96, 96), (8200, 576, 192), (8193, 192, 192), (8200, 768, 192),
+                                   (8250, 128, 128), (8200, 384, 128), (9000, 64, 96)])
 def test_linear_requant_epilogues_vs_oracle(H, M, N, K):
     """a1+a3 fused epilogues (8-bit, 16-bit, 16-bit + residual) == oracle linear + requant.
     K % 32 == 0 (K >= 64) shapes take the global_load_lds kernel — K % 64 == 32 through its masked 32-wide
@@ -243,6 +247,27 @@ def test_linear_requant_epilogues_vs_oracle(H, M, N, K):
         ref = orc.requant(t, orc.dyadic(np.float32(s_mid), np.float32(s_fin)), 16, res.astype(np.int32),
                           orc.dyadic(np.float32(s_res), np.float32(s_fin)))
         assert np.array_equal(out.cpu().numpy().astype(np.int32), ref), (M, N, K, s_mid)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 288, 96), (8300, 288, 96), (8200, 192, 192)])
+def test_linear_requant_saturating_multipliers(H, M, N, K):
+    """multipliers far outside the magic-number range (|z c| >= 2^31 possible): every kernel of the QuantLinear family must
+    take its v_rndne_f64 / saturating-convert path and still clamp like the reference (quant_utils.py:247-251)"""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(N + K)
+    x = rng.integers(-128, 128, (M, K), dtype=np.int8)
+    w = rng.integers(-128, 128, (N, K), dtype=np.int8)
+    b = rng.integers(-2 ** 16, 2 ** 16, N).astype(np.int32)
+    acc = orc.linear_i8(x, w, b)
+    s_pre = (10 ** rng.uniform(-3, -2, N)).astype(np.float32)
+    s_pre[::7] = np.float32(3e-9)                      # a few channels stay in range: mixed group
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    for bits in (8, 16):
+        d = iv.freeze.dyadic(s_pre, np.float32(2e-7))
+        out = torch.empty(M, N, dtype={8: torch.int8, 16: torch.int16}[bits], device="cuda")
+        H.call("ivit_linear_i8_requant", P(xd), P(wd), P(bd), P(dev(d)), bits, P(out), M, N, K)
+        ref = orc.requant(acc, orc.dyadic(s_pre, np.float32(2e-7)), bits)
+        assert np.array_equal(out.cpu().numpy().astype(np.int32), ref), (bits, M, N, K)
 
 
 def test_mfma_operand_order_asymmetric(H):
