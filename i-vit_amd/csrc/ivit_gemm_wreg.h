@@ -117,6 +117,16 @@ __global__ __launch_bounds__(GW_THREADS, GW_MINW(EPI, KS, NCT)) void gemm_wreg_k
             for (int ks = 0; ks < KS; ++ks) af[ks] = *(lds_v4i *)(size_t)(fa + buf * ABUF + ks * GW_BM * 32);
             const long long row = rt * GW_BM + wave * 32 + tok;
             const bool live = row < p.M;
+            // identity rows of all NCT tiles requested together, ahead of the MFMAs (one exposed latency per row tile, not NCT)
+            v4i res[EPI == EPI_RQ16_CH_RES ? NCT : 1][2];
+            if (EPI == EPI_RQ16_CH_RES) {
+                const int16_t *rp = p.residual + min(row, (long long)p.M - 1) * p.ldc + chbase + 16 * kh;
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    res[ct][0] = *reinterpret_cast<const v4i *>(rp + 32 * ct);
+                    res[ct][1] = *reinterpret_cast<const v4i *>(rp + 32 * ct + 8);
+                }
+            }
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
                 v16i acc;
@@ -128,12 +138,7 @@ __global__ __launch_bounds__(GW_THREADS, GW_MINW(EPI, KS, NCT)) void gemm_wreg_k
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[ct][ks], af[ks], acc, 0, 0, 0);
                 const int ch0 = chbase + 32 * ct + 16 * kh;
-                v4i r0 = {0, 0, 0, 0}, r1 = {0, 0, 0, 0};
-                if (EPI == EPI_RQ16_CH_RES && live) {
-                    const int16_t *rp = p.residual + row * p.ldc + ch0;
-                    r0 = *reinterpret_cast<const v4i *>(rp);
-                    r1 = *reinterpret_cast<const v4i *>(rp + 8);
-                }
+                const v4i r0 = res[EPI == EPI_RQ16_CH_RES ? ct : 0][0], r1 = res[EPI == EPI_RQ16_CH_RES ? ct : 0][1];
                 int o[16];
 #pragma unroll
                 for (int v = 0; v < 16; v += 2) {
