@@ -321,6 +321,7 @@ struct ivit_swin_s {
     bool fused_mlp;                   // stage-0 Mlp in one kernel (ivit_mlp_fused)
     std::vector<ivit_linear_plan> mlp_lin;   // per block: fc1, fc2 plans of the C = 384 stage (null elsewhere)
     std::vector<ivit_mlp_plan> mlp_plans;    // per block: fused Mlp plan (C = 384, hidden 1536) or null
+    std::vector<ivit_linear_plan> lin_plans; // per block: qkv, proj, fc1, fc2 plans where C % 384 == 0 (IVIT_OPT_SWIN_PLANS), else null
     int8_t *gelu_tab;                 // [nblocks][65536]
     int max_slices;
     std::vector<ivit_handle> slice_h;
@@ -328,6 +329,10 @@ struct ivit_swin_s {
     std::vector<hipEvent_t> done;
     hipEvent_t fork;
 };
+
+#ifndef IVIT_OPT_SWIN_PLANS
+#define IVIT_OPT_SWIN_PLANS 0          // A/B: the C = 384 / 768 stages' QuantLinear layers on the planned (persistent) kernels
+#endif
 
 namespace {
 
@@ -386,7 +391,9 @@ int swin_run_slice(const ivit_swin_s *m, ivit_handle h, const int8_t *images, in
             const ivit_swin_block &b = m->blocks[bi];
             const int shift = (bj % 2 == 0 || res <= c.window_size) ? 0 : c.window_size / 2;
             RUN(swin_ln(m, h, x, M, C, b.s_in, b.n1, L, li == 0, a8));
-            RUN(ivit_linear_i8_requant(h, a8, b.qkv.w, b.qkv.b, b.qkv.dy, 8, qkv, (int)M, 3 * C, C));
+            const ivit_linear_plan *lp = m->lin_plans.empty() ? nullptr : &m->lin_plans[4 * bi];
+            if (lp && lp[0]) RUN(ivit_linear_i8_requant_planned(h, lp[0], a8, 8, qkv, (int)M));
+            else RUN(ivit_linear_i8_requant(h, a8, b.qkv.w, b.qkv.b, b.qkv.dy, 8, qkv, (int)M, 3 * C, C));
             if (b.exp_aq)
                 RUN(ivit_window_attention_fused_lut(h, qkv, b.dy_qk, b.dy_a, b.relb, b.s_softmax, b.exp_aq, b.exp_t, b.exp_cls,
                                                     b.exp_nc, b.exp_tcount, b.exp_dmin, b.dy_pv, ctx, B, res, c.window_size,
@@ -394,7 +401,8 @@ int swin_run_slice(const ivit_swin_s *m, ivit_handle h, const int8_t *images, in
             else
                 RUN(ivit_window_attention_fused(h, qkv, b.dy_qk, b.dy_a, b.relb, b.s_softmax, b.dy_pv, ctx, B, res,
                                                 c.window_size, shift, heads, C / heads));
-            RUN(ivit_linear_i8_requant_residual(h, ctx, b.proj.w, b.proj.b, b.proj.dy, b.res1_main, b.res1_res, x, y, (int)M, C, C));
+            if (lp && lp[1]) RUN(ivit_linear_i8_requant_residual_planned(h, lp[1], ctx, b.res1_main, b.res1_res, x, y, (int)M));
+            else RUN(ivit_linear_i8_requant_residual(h, ctx, b.proj.w, b.proj.b, b.proj.dy, b.res1_main, b.res1_res, x, y, (int)M, C, C));
             { int16_t *t = x; x = y; y = t; }
             RUN(swin_ln(m, h, x, M, C, b.s_mid, b.n2, L, li == 0, a8));
             const bool mlp384 = m->mlp_plans[bi] && fabs(b.res2_main.m * b.res2_main.r) < RQ_FAST_CLIM &&
@@ -405,9 +413,11 @@ int swin_run_slice(const ivit_swin_s *m, ivit_handle h, const int8_t *images, in
             } else if (mlp384) {                                    // C = 384 stage: weights streamed, hidden tile in LDS
                 RUN(ivit_mlp_fused_planned(h, m->mlp_plans[bi], a8, m->gelu_tab + (size_t)bi * 65536, b.res2_main, b.res2_res, x, y, M));
             } else {
-                RUN(ivit_linear_i8_requant(h, a8, b.fc1.w, b.fc1.b, b.fc1.dy, 8, h8, (int)M, c.mlp_ratio * C, C));
+                if (lp && lp[2]) RUN(ivit_linear_i8_requant_planned(h, lp[2], a8, 8, h8, (int)M));
+                else RUN(ivit_linear_i8_requant(h, a8, b.fc1.w, b.fc1.b, b.fc1.dy, 8, h8, (int)M, c.mlp_ratio * C, C));
                 RUN(ivit_shiftgelu_requant_lut(h, h8, M, c.mlp_ratio * C, m->gelu_tab + (size_t)bi * 65536, g8));
-                RUN(ivit_linear_i8_requant_residual(h, g8, b.fc2.w, b.fc2.b, b.fc2.dy, b.res2_main, b.res2_res, x, y, (int)M, C, c.mlp_ratio * C));
+                if (lp && lp[3]) RUN(ivit_linear_i8_requant_residual_planned(h, lp[3], g8, b.res2_main, b.res2_res, x, y, (int)M));
+                else RUN(ivit_linear_i8_requant_residual(h, g8, b.fc2.w, b.fc2.b, b.fc2.dy, b.res2_main, b.res2_res, x, y, (int)M, C, c.mlp_ratio * C));
             }
             { int16_t *t = x; x = y; y = t; }
         }
@@ -443,6 +453,7 @@ int ivit_swin_destroy(ivit_swin m) {
     if (m->gelu_tab) (void)hipFree(m->gelu_tab);
     for (auto mp : m->mlp_plans) if (mp) (void)ivit_mlp_plan_destroy(mp);
     for (auto pl : m->mlp_lin) if (pl) (void)ivit_linear_plan_destroy(pl);
+    for (auto pl : m->lin_plans) if (pl) (void)ivit_linear_plan_destroy(pl);
     delete m;
     return IVIT_OK;
 }
@@ -504,6 +515,18 @@ int ivit_swin_create(ivit_handle h, const ivit_swin_config *cfg, const ivit_swin
                 m->mlp_lin.push_back(p1);
                 m->mlp_lin.push_back(p2);
                 m->mlp_plans.push_back(mp);
+                if (IVIT_OPT_SWIN_PLANS) {
+                    ivit_linear_plan q[4] = {nullptr, nullptr, nullptr, nullptr};
+                    if (C % 384 == 0) {
+                        if (ivit_linear_plan_create(h, b.qkv.w, b.qkv.b, b.qkv.dy, 3 * C, C, &q[0]) != IVIT_OK) q[0] = nullptr;
+                        if (ivit_linear_plan_create(h, b.proj.w, b.proj.b, b.proj.dy, C, C, &q[1]) != IVIT_OK) q[1] = nullptr;
+                        if (!mp) {
+                            if (ivit_linear_plan_create(h, b.fc1.w, b.fc1.b, b.fc1.dy, cfg->mlp_ratio * C, C, &q[2]) != IVIT_OK) q[2] = nullptr;
+                            if (ivit_linear_plan_create(h, b.fc2.w, b.fc2.b, b.fc2.dy, C, cfg->mlp_ratio * C, &q[3]) != IVIT_OK) q[3] = nullptr;
+                        }
+                    }
+                    for (int k = 0; k < 4; ++k) m->lin_plans.push_back(q[k]);
+                }
             }
     }
     if (max_slices > 1) {
