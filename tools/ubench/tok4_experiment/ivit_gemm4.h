@@ -1,3 +1,5 @@
+// NUMERICALLY WRONG AS IT STANDS (round 4: the probe's equality check against the shipped kernel is RED — its 12-byte global_load_lds_dwordx3
+// pieces were never validated): a timing experiment kept for its measurements (profiles/README.md, round 4), outside the build.
 // ivit_gemm4.h — token-stationary QuantLinear for K = 384 (the qkv projection of DeiT-S / Swin stage 2):
 //   out = requant((x (M x 384 int8) * W^T + bias) * c) scattered into q / k / v^T        (quant_modules.py:67-97, vit_quant.py:64-68)
 //

@@ -1,3 +1,4 @@
+// NUMERICALLY WRONG AS IT STANDS: the equality check below is RED (see ivit_gemm4.h); timing experiment only, outside the build.
 // Stand-alone check + timing of tok4_qkv_kernel (ivit_gemm4.h) against a plain reference kernel, random operands.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/ubench/tok4_probe.hip -o tools/ubench/tok4_probe
 #include "ivit_gemm4.h"
