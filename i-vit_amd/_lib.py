@@ -9,7 +9,7 @@ import subprocess
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 SO_PATH = os.environ.get("IVIT_LIB") or os.path.join(_CSRC, "libivit_hip.so")
-SOURCES = ["ivit_hip.hip", "ivit_device.h", "ivit_gemm.h", "ivit_elementwise.h", "ivit_layernorm.h", "ivit_attention.h", "ivit_gemm2.h", "ivit_gemm3.h", "ivit_gemm_wreg.h", "ivit_swin.h", "ivit_mlp.h", "ivit_mlp_rs.h", "ivit_model.h"]
+SOURCES = ["ivit_hip.hip", "ivit_device.h", "ivit_gemm.h", "ivit_elementwise.h", "ivit_layernorm.h", "ivit_attention.h", "ivit_gemm2.h", "ivit_gemm3.h", "ivit_gemm_wreg.h", "ivit_swin.h", "ivit_mlp.h", "ivit_mlp_rs.h", "ivit_swin_mlp_rs.h", "ivit_model.h"]
 _THIS = os.path.abspath(__file__)
 # -packed-fp32-ops: no v_pk_{add,mul,fma}_f32 anywhere in the library.  Round 4 traced the sporadic one-LSB differences of
 # layernorm_reg_kernel<192, 1> beside QuantLinear GEMM workgroups to that instruction class (profiles/README.md round 4: the

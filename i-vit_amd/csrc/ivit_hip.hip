@@ -19,6 +19,7 @@
 #include "ivit_swin.h"
 #include "ivit_mlp.h"
 #include "ivit_mlp_rs.h"
+#include "ivit_swin_mlp_rs.h"
 
 struct ivit_ctx {
     int device;
@@ -627,6 +628,9 @@ int ivit_linear_i8_qkv_planned(ivit_handle h, ivit_linear_plan pl, const int8_t 
 
 }  // extern "C"
 
+#ifndef IVIT_OPT_SWIN_MLP_RS
+#define IVIT_OPT_SWIN_MLP_RS 1          // A/B builds: 0 = the narrow-stage fused Mlp always on the phase-by-phase kernel
+#endif
 // ---- fused Mlp (+ residual QuantAct) for D = 384, hidden = 1536 (ivit_mlp.h)
 #ifndef IVIT_OPT_MLP_RS
 #define IVIT_OPT_MLP_RS 1               // A/B builds: 0 = the shape-based default never picks the role-split kernel
@@ -1229,6 +1233,7 @@ int ivit_mlp_fused(ivit_handle h, const int8_t *x, const int8_t *w1, const int32
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute((const void *)swin_mlp_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MF_SMEM);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)swin_mlp_rs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SR_SMEM);
         if (e != hipSuccess) { snprintf(h->err, sizeof(h->err), "mlp_fused attr: %s", hipGetErrorString(e)); return IVIT_ERR_HIP; }
         attr = true;
     }
@@ -1237,7 +1242,10 @@ int ivit_mlp_fused(ivit_handle h, const int8_t *x, const int8_t *w1, const int32
     a.dy_main = dy_main; a.dy_res = dy_res; a.residual = residual; a.out = out; a.M = M;
     const long long ntiles = (M + MF_BM - 1) / MF_BM;
     const unsigned grid = (unsigned)(ntiles < h->num_cu ? ntiles : h->num_cu);
-    swin_mlp_fused_kernel<<<grid, MF_THREADS, MF_SMEM, h->stream>>>(a);
+    // role-split form (ivit_swin_mlp_rs.h: producers on fc1 of tile i + 1 beside consumers on ShiftGELU / fc2 of tile i) when a
+    // workgroup has at least two tiles to overlap; the phase-by-phase kernel otherwise
+    if (IVIT_OPT_SWIN_MLP_RS && ntiles >= 2 * (long long)grid) swin_mlp_rs_kernel<<<grid, SR_THREADS, SR_SMEM, h->stream>>>(a);
+    else swin_mlp_fused_kernel<<<grid, MF_THREADS, MF_SMEM, h->stream>>>(a);
     LAUNCH_CHECK(h);
     return IVIT_OK;
 }
