@@ -134,6 +134,11 @@ if not os.environ.get("SWIN_ONLY"):
     mpv = _P(); hs[0].call("ivit_mlp_plan_create", p1, p2, ctypes.byref(mpv))
     stress("ivit_mlp_fused_planned", lambda: torch.empty(Mv, D, dtype=torch.int16, device="cuda"),
            lambda h, o: h.call("ivit_mlp_fused_planned", mpv, P(xa), P(tabv), dyv(dmv), dyv(drv), P(resv), P(o), Mv), None)
+    # round 5: row counts that reach the role-split kernels (two 80-token units per CU; two 64-token tiles per workgroup)
+    Mr = 128 * T
+    xr = dev(rng.integers(-128, 128, (Mr, D), dtype=np.int8)); resr = dev(rng.integers(-30000, 30000, (Mr, D)).astype(np.int16))
+    stress("ivit_mlp_fused_planned M=25216 (role-split)", lambda: torch.empty(Mr, D, dtype=torch.int16, device="cuda"),
+           lambda h, o: h.call("ivit_mlp_fused_planned", mpv, P(xr), P(tabv), dyv(dmv), dyv(drv), P(resr), P(o), Mr), None)
     h8v = dev(rng.integers(-128, 128, (Mv, Hd), dtype=np.int8))
     stress("ivit_shiftgelu_requant_lut", lambda: torch.empty(Mv, Hd, dtype=torch.int8, device="cuda"),
            lambda h, o: h.call("ivit_shiftgelu_requant_lut", P(h8v), Mv, Hd, P(tabv), P(o)), None)
@@ -161,6 +166,9 @@ if not os.environ.get("SWIN_ONLY"):
     d1s = dev(iv.freeze.dyadic((10 ** rng.uniform(-5.0, -4.6, 384)).astype(np.float32), np.float32(0.012)))
     d2s = dev(iv.freeze.dyadic((10 ** rng.uniform(-5.3, -4.9, 96)).astype(np.float32), np.float32(2e-4)))
     res96 = dev(rng.integers(-30000, 30000, (M // 4, 96)).astype(np.int16))
+    x96b = dev(rng.integers(-128, 128, (M, 96), dtype=np.int8)); res96b = dev(rng.integers(-30000, 30000, (M, 96)).astype(np.int16))
+    stress("ivit_mlp_fused C=96 M=100352 (role-split)", lambda: torch.empty(M, 96, dtype=torch.int16, device="cuda"),
+           lambda h, o: h.call("ivit_mlp_fused", P(x96b), P(w1s), P(b1s), P(d1s), P(tabv), P(w2s), P(b2s), P(d2s), dyv(dmv), dyv(drv), P(res96b), P(o), M, 96, 384), None)
     stress("ivit_mlp_fused C=96", lambda: torch.empty(M // 4, 96, dtype=torch.int16, device="cuda"),
            lambda h, o: h.call("ivit_mlp_fused", P(x96), P(w1s), P(b1s), P(d1s), P(tabv), P(w2s), P(b2s), P(d2s), dyv(dmv), dyv(drv), P(res96), P(o), M // 4, 96, 384), None)
 
