@@ -12,9 +12,10 @@ SO_PATH = os.environ.get("IVIT_LIB") or os.path.join(_CSRC, "libivit_hip.so")
 SOURCES = ["ivit_hip.hip", "ivit_device.h", "ivit_gemm.h", "ivit_elementwise.h", "ivit_layernorm.h", "ivit_attention.h", "ivit_gemm2.h", "ivit_gemm3.h", "ivit_gemm_wreg.h", "ivit_swin.h", "ivit_mlp.h", "ivit_mlp_rs.h", "ivit_swin_mlp_rs.h", "ivit_model.h"]
 _THIS = os.path.abspath(__file__)
 # -packed-fp32-ops: no v_pk_{add,mul,fma}_f32 anywhere in the library.  Round 4 traced the sporadic one-LSB differences of
-# layernorm_reg_kernel<192, 1> beside QuantLinear GEMM workgroups to that instruction class (profiles/README.md round 4: the
-# same kernel built without packed fp32 is clean in 20 000 stress launches; replacing its DPP reductions by ds_bpermute is not);
-# the flag costs < 1 % (DeiT-B) and tests/test_cabi_cpu.py::test_no_packed_fp32_in_library keeps it in place.
+# layernorm_reg_kernel<192, 1> beside QuantLinear GEMM workgroups to that instruction class; round 5 to one form of it:
+# v_pk_{add,mul}_f32 with op_sel:[0,1] reads src1's high dword as 0 on lanes 48..63 while another wave of the SIMD has MFMAs in
+# flight (profiles/r05_hazard/README.md, tools/ubench/pk_opsel_hazard.hip).  The flag costs < 1 % (DeiT-B) and
+# tests/test_cabi_cpu.py::test_no_packed_fp32_in_library keeps it in place.
 # Scoping (the unscoped -Xclang pair also reaches the x86 host compile, which prints "not a recognized feature ...
 # ignoring" per function): -Xarch_device refuses to forward cc1 options ("options requiring arguments are unsupported"), and the
 # source-level form — target("no-packed-fp32-ops") on every function of the device pass by #pragma clang attribute — produces

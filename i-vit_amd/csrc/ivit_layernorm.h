@@ -45,12 +45,12 @@ __device__ __forceinline__ float ln_dpp(float v) {
 }
 
 // S = 1 (4 lanes per row, quad_perm broadcasts) is NOT dispatched (S = 2 is the faster form) and does not compile outside the
-// probe build (-DIVIT_PROBE_LN192_S1=1, tools/ln_s1_probe.sh).  History: it returned one-LSB differences in a few adjacent rows
-// in 1-4 % of the launches that shared CUs with QuantLinear GEMM workgroups.  Round 4 narrowed that to the packed-fp32
-// instructions hipcc used in its sums (v_pk_add/mul/fma_f32; the S = 2 ISA has none): built without packed fp32 it is clean in
-// 20 000 stress launches, with s_nop 7 around each reduction group too; with ds_bpermute instead of DPP, or with the channel
-// constants read from global memory instead of LDS, it still fails.  The library is now built with -packed-fp32-ops off
-// (i-vit_amd/_lib.py), which also covers the S = 4 forms and the token-order kernels whose ISA had packed fp32.
+// probe build (-DIVIT_PROBE_LN192_S1=1, tools/ln_s1_probe.sh, tools/ubench/ln_s1_standalone.hip).  History: it returned one-LSB
+// differences in rows 12..15 of a wave in 1-4 % of the launches that shared a SIMD with MFMA-issuing waves.  Round 5 reduced that
+// to one instruction form hipcc used in its running sums — v_pk_add_f32 ... op_sel:[0,1] op_sel_hi:[1,0], whose low lane takes
+// src1's HIGH dword: beside MFMAs that dword is occasionally read as 0 on lanes 48..63 (profiles/r05_hazard/README.md,
+// tools/ubench/pk_opsel_hazard.hip).  The library is built with -packed-fp32-ops off (i-vit_amd/_lib.py), which removes the form
+// here, in the S = 4 kernels and in the token-order kernels whose ISA had packed fp32.
 // 32 rows per block whatever the split: the per-block staging of the channel constants (an fp64 division each) stays ~8 %
 #ifndef LNR_TB
 #define LNR_TB 128
