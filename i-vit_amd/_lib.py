@@ -43,10 +43,23 @@ def build(force=False, verbose=False):
     if not force and os.path.exists(SO_PATH) and os.path.getmtime(SO_PATH) >= newest:
         return SO_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + [os.path.join(_CSRC, "ivit_hip.hip"), "-o", SO_PATH]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    # one builder at a time (the ranks of a multi-GPU launch import this module together), and the library appears atomically:
+    # a rank that lost the race finds it up to date once it holds the lock
+    import fcntl
+    with open(SO_PATH + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and os.path.exists(SO_PATH) and os.path.getmtime(SO_PATH) >= newest:
+            return SO_PATH
+        tmp = "%s.%d.tmp" % (SO_PATH, os.getpid())
+        cmd = [hipcc] + HIPCC_FLAGS + [os.path.join(_CSRC, "ivit_hip.hip"), "-o", tmp]
+        if verbose:
+            print(" ".join(cmd))
+        try:
+            subprocess.check_call(cmd)
+            os.replace(tmp, SO_PATH)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
     return SO_PATH
 
 
