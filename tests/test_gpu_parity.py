@@ -1569,13 +1569,15 @@ def test_swin_sliced_concurrency_stress():
 
 def test_layernorm_beside_gemms_concurrency(H):
     """Every dispatched layernorm_reg_kernel shape launched on 8 streams at once, interleaved with QuantLinear GEMMs on the
-    same streams: each output equals the single-stream result (tools/op_stress.py is the long form)."""
+    same streams: each output equals the single-stream result (tools/op_stress.py is the long form).  The K = 48 shape is the
+    patch-embedding GEMM on gemm_nt_kernel (MFMA accumulators in AGPRs): the aggressor beside which the packed-fp32 form of the
+    S = 1 LayerNorm failed in up to 40 % of its launches (profiles/r05_hazard/README.md)."""
     rng = np.random.default_rng(3)
     NS = 8
     streams = [torch.cuda.Stream() for _ in range(NS)]
     hs = [_lib.Handle(0, st.cuda_stream) for st in streams]
     ops = []
-    for (K, N, M) in ((96, 288, 50176), (384, 1152, 6272)):
+    for (K, N, M) in ((96, 288, 50176), (384, 1152, 6272), (48, 96, 100352)):
         x = dev(rng.integers(-128, 128, (M, K), dtype=np.int8)); w = dev(rng.integers(-128, 128, (N, K), dtype=np.int8))
         b = dev(rng.integers(-3000, 3000, N).astype(np.int32))
         d = dev(iv.freeze.dyadic((10 ** rng.uniform(-5.6, -5.2, N)).astype(np.float32), np.float32(0.012)))
