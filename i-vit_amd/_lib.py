@@ -22,6 +22,8 @@ _THIS = os.path.abspath(__file__)
 # the same 0 v_pk instructions but a 35 % slower DeiT-S forward (4.61 vs 3.02 ms on one box: differing target features keep the
 # inliner away from the __forceinline__ helpers), so the command-line form stays; the host-side warning is harmless and the ISA
 # test fails if a toolchain ever turns it into a dropped flag.
+# gfx950 only, SRAM-ECC on (the only mode MI355X ships in): ivit_mlp_rs.h / ivit_swin_mlp_rs.h rely on ds_read_u8_d16_hi ZEROING the low
+# half of its destination, which is the d16 behaviour of SRAM-ECC parts; a target without it would need the merge written out.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-pass-failed", "-fPIC", "-shared",
                "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 

@@ -38,11 +38,20 @@ __device__ __forceinline__ int clamp_b(double v) {
     return (int)v;
 }
 
+// rne to int32, SATURATING: v_rndne_f64 + v_cvt_i32_f64.  The C++ cast of an out-of-range double is undefined behaviour; the
+// requant paths below rely on the instruction's saturation (|z * c| may exceed 2^31 before the clamp), so the instruction is
+// named instead of implied.  tests/test_gpu_parity.py::test_linear_requant_saturating_multipliers pins it.
+__device__ __forceinline__ int rint_sat_i32(double t) {
+    int v;
+    asm("v_cvt_i32_f64 %0, %1" : "=v"(v) : "v"(__builtin_rint(t)));
+    return v;
+}
+
 // lean form of the same requant: c = m*2^-e is exact in fp64 (m integer <= 2^31, power-of-two
 // scaling), so fl64(z*c) == fl64(z*m)*2^-e: one v_mul_f64; v_cvt_i32_f64 saturates and the
 // clamp is an integer med3.  Bit-identical to rq_f64 + clamp_b.
 __device__ __forceinline__ int rq_c(double z, double c, int lo, int hi) {
-    int v = (int)__builtin_rint(z * c);
+    int v = rint_sat_i32(z * c);
     return min(max(v, lo), hi);
 }
 

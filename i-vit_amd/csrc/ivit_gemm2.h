@@ -41,10 +41,10 @@ template <int BM> struct G2Cfg {
 #define G2_LD16 264             // staged int16 row stride (bytes): conflict-free ds_write_b64
 
 __device__ __forceinline__ int rq_lean(int z, double c, int lo, int hi) {
-    int v = (int)__builtin_rint((double)z * c);   // cvt_i32_f64 saturates
+    int v = rint_sat_i32((double)z * c);
     return min(max(v, lo), hi);
 }
-__device__ __forceinline__ int rq_lean_wide(int z, double c) { return (int)__builtin_rint((double)z * c); }
+__device__ __forceinline__ int rq_lean_wide(int z, double c) { return rint_sat_i32((double)z * c); }
 
 // kchunks: valid 16-byte chunks of this K step (4, or 2 for the 32-wide tail step when K % 64 == 32): lanes whose
 // chunk lies beyond K are masked off — their LDS slots keep stale bytes that the tail step never feeds to an MFMA
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 4 : (G2_NSTAGE128 == 2 ? 4 : 3)
                         const int z = acc[i][j][g * 4 + e] + bs[e];
                         if (p.dbg == 3) { o[e] = z; continue; }   // ablation: no requant math
                         const double t = (double)z * c[e];
-                        const int v = decltype(use_fast)::value ? __double2loint(t + 6755399441055744.0) : (int)__builtin_rint(t);
+                        const int v = decltype(use_fast)::value ? __double2loint(t + 6755399441055744.0) : rint_sat_i32(t);
                         o[e] = min(max(v, OLO), OHI);
                     }
                     if (OUT8) {

@@ -147,7 +147,7 @@ __global__ __launch_bounds__(GW_THREADS, GW_MINW(EPI, KS, NCT)) void gemm_wreg_k
                     for (int e = 0; e < 2; ++e) {
                         const double t = (double)acc[v + e] * c2[e];
                         if (decltype(use_fast)::value) o[v + e] = __double2loint(t + (6755399441055744.0 + (OUT8 ? 128.0 : 0.0)));
-                        else o[v + e] = min(max((int)__builtin_rint(t), OUT8 ? -128 : -32768), OUT8 ? 127 : 32767) + (OUT8 ? 128 : 0);   // v_cvt_i32_f64 saturates
+                        else o[v + e] = min(max(rint_sat_i32(t), OUT8 ? -128 : -32768), OUT8 ? 127 : 32767) + (OUT8 ? 128 : 0);
                     }
                 }
                 if (OUT8) {

@@ -8,6 +8,7 @@
 #include <new>
 #include <dlfcn.h>
 #include <mutex>
+#include <atomic>
 #include "ivit_device.h"
 #include "ivit_elementwise.h"
 #include "ivit_layernorm.h"
@@ -21,6 +22,7 @@
 #include "ivit_mlp_rs.h"
 #include "ivit_swin_mlp_rs.h"
 
+#define IVIT_MAX_DEVICES 64     // per-device caches of launch attributes (larger ordinals simply do not cache)
 struct ivit_ctx {
     int device;
     hipStream_t stream;
@@ -214,11 +216,16 @@ static inline int wreg_nct(const GemmArgs &a) {
 template <int EPI, int KS, int NCT>
 static int launch_wreg_k(ivit_handle h, const GemmArgs &a) {
     const int ncg = a.N / (32 * NCT);
-    static int wpc = 0;                              // resident workgroups per CU of this instantiation (registers, LDS): once
+    // resident workgroups per CU of this instantiation (registers, LDS): asked once PER DEVICE (a process-wide
+    // static reused the first device's answer on every other one); a race between host threads stores the same value twice
+    static std::atomic<int> wpc_dev[IVIT_MAX_DEVICES];
+    const bool cached = h->device >= 0 && h->device < IVIT_MAX_DEVICES;
+    int wpc = cached ? wpc_dev[h->device].load(std::memory_order_relaxed) : 0;
     if (!wpc) {
         int n = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_wreg_kernel<EPI, KS, NCT>, GW_THREADS, 0) != hipSuccess || n < 1) n = 1;
         wpc = n;
+        if (cached) wpc_dev[h->device].store(n, std::memory_order_relaxed);
     }
     int per = (h->num_cu * wpc) / (8 * ncg);
     if (per < 1) per = 1;
@@ -1230,12 +1237,14 @@ int ivit_mlp_fused(ivit_handle h, const int8_t *x, const int8_t *w1, const int32
         snprintf(h->err, sizeof(h->err), "%s: built for C = 96, hidden = 384 (weights resident in LDS)", __func__);
         return IVIT_ERR_UNSUPPORTED;
     }
-    static bool attr = false;
-    if (!attr) {
+    // the dynamic-LDS attribute is per device (one process-wide flag left the second GPU of a process without it)
+    static std::atomic<bool> attr_dev[IVIT_MAX_DEVICES];
+    const bool cached = h->device >= 0 && h->device < IVIT_MAX_DEVICES;
+    if (!cached || !attr_dev[h->device].load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute((const void *)swin_mlp_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MF_SMEM);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void *)swin_mlp_rs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SR_SMEM);
         if (e != hipSuccess) { snprintf(h->err, sizeof(h->err), "mlp_fused attr: %s", hipGetErrorString(e)); return IVIT_ERR_HIP; }
-        attr = true;
+        if (cached) attr_dev[h->device].store(true, std::memory_order_release);
     }
     MlpFusedArgs a;
     a.x = x; a.w1 = w1; a.b1 = b1; a.dy1 = dy1; a.tab = gelu_table; a.w2 = w2; a.b2 = b2; a.dy2 = dy2;

@@ -75,78 +75,18 @@ __device__ __forceinline__ float ln_dpp(float v) {
 #define LNR_W48 5
 #endif
 #define LNR_MIN_WAVES(CC, S) (LNR_VPL(CC, S) <= 24 ? 8 : (LNR_VPL(CC, S) <= 48 ? LNR_W48 : (LNR_VPL(CC, S) <= 64 ? 4 : 3)))
+// Everything after the row is in registers as x = fl(fl(Q*s)/s): both torch-order sums, the integer Newton iteration, the
+// output pass with the per-channel constants of the block's LDS copy, the store.  Shared by the one-shot kernel and the
+// pipelined one below.
 template <int CC, int S>
-__global__ __launch_bounds__(LNR_THREADS(S), LNR_MIN_WAVES(CC, S)) void layernorm_reg_kernel(const int16_t *__restrict__ x, long long rows,
-                                                                     long long row_stride, float s,
-                                                                     const float *__restrict__ bias_int,
-                                                                     const float *__restrict__ sc,
-                                                                     const ivit_dyadic *__restrict__ dy,
-                                                                     int8_t *__restrict__ out) {
-#if !IVIT_PROBE_LN192_S1
-    static_assert(S != 1, "the 4-lanes-per-row form is a probe (see the note above)");
-#endif
-    constexpr int LPR = 4 * S, EPC = 8 / S, NSTEP = CC / 32, RPW = 64 / LPR, RPB = (LNR_THREADS(S) / 64) * RPW;
+struct LnGroup {
+    static constexpr int LPR = 4 * S, EPC = 8 / S, NSTEP = CC / 32, RPW = 64 / LPR;
     static_assert(CC % 32 == 0 && NSTEP < 256, "whole 32-element steps, at most one cascade level above the first");
-    __shared__ __attribute__((aligned(16))) double cC[CC];
-    __shared__ __attribute__((aligned(16))) float cB[CC], cSc[CC], cY[CC];
-    const int tid = threadIdx.x;
-    // The 8-bit requant rne(fl64(z * c)) is taken as the low dword of fl64(z * c) + (1.5 * 2^52 + 128) — the same two roundings
-    // as the reference (quant_utils.py:229-231) in two fp64 operations instead of four, biased to 0..255 so the four bytes of
-    // a dword pack without masks.  That needs |z * c| < 2^31: |y| <= 2^16 and k >= 2^16 / 2^10 after ten halvings at most bound
-    // |o| by 2^40 + |bias|; a block with a channel where that bound fails keeps v_rndne_f64 + the saturating v_cvt_i32_f64.
-    bool wide = false;
-    for (int c = tid; c < CC; c += LNR_THREADS(S)) {
-        const float scv = sc[c], bv = bias_int[c];
-        const double cv = dy[c].m * dy[c].r;
-        cSc[c] = scv;
-        cY[c] = rcp_rn(scv);
-        cB[c] = bv;
-        cC[c] = cv;
-        wide |= !(fabs(cv) * (1.2e12 + 1.01 * fabs((double)bv)) < 2147483000.0);
-    }
-    const bool fastrq = !__syncthreads_or(wide);
-    const int lane = tid & 63, j = lane % LPR, k = j / S, hh = j % S;
-    const long long row_raw = (long long)blockIdx.x * RPB + (tid >> 6) * RPW + lane / LPR;
-    const bool live = row_raw < rows;
-    const long long row = live ? row_raw : rows - 1;          // a dead lane group recomputes the last row, stores nothing
-    const int16_t *xp = x + row * row_stride + 8 * k + EPC * hh;
-    const float ys = rcp_rn(s);
 
-    // ---- pass 1: load, x = fl(fl(Q*s)/s), first sum
-    float xv[NSTEP][EPC];
-    float a0[EPC], a1[EPC];
-#pragma unroll
-    for (int e = 0; e < EPC; ++e) { a0[e] = 0.f; a1[e] = 0.f; }
-#pragma unroll
-    for (int i = 0; i < NSTEP; ++i) {
-        short q[EPC];
-        if constexpr (EPC == 8) {
-            const v8s t = *reinterpret_cast<const v8s *>(xp + 32 * i);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) q[e] = t[e];
-        } else if constexpr (EPC == 4) {
-            typedef short v4s __attribute__((ext_vector_type(4)));
-            const v4s t = *reinterpret_cast<const v4s *>(xp + 32 * i);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) q[e] = t[e];
-        } else {
-            typedef short v2s __attribute__((ext_vector_type(2)));
-            const v2s t = *reinterpret_cast<const v2s *>(xp + 32 * i);
-            q[0] = t[0]; q[1] = t[1];
-        }
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) xv[i][e] = requotient_m((float)q[e], s, ys);
-    }
-    auto cascade = [&](int i) {      // torch's level-1 fold after every 16 whole steps
-        if (((i + 1) & 15) == 0 && i + 1 <= (NSTEP & ~15)) {
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) { a1[e] += a0[e]; a0[e] = 0.f; }
-        }
-    };
     // ((g0 + g1) + g2) + g3 over the accumulator groups, then vector lanes 0..7 in order; every lane of the row gets it.
     // Lane j = S k + h of a row: group k + 1 is S lanes up (DPP row shifts; a row's 4 S lanes never straddle a DPP row of
     // 16), the partial sums are valid on the k = 0 lanes, the total on lane j = 0, from where it is broadcast.
-    auto finish = [&]() -> float {
+    static __device__ __forceinline__ float finish(const float (&a0)[EPC], const float (&a1)[EPC], int j, int k) {
         float p[EPC];
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
@@ -200,104 +140,182 @@ __global__ __launch_bounds__(LNR_THREADS(S), LNR_MIN_WAVES(CC, S)) void layernor
             fin = k == 0 ? q0 : (k == 1 ? q1 : (k == 2 ? q2 : q3));
         }
         return fin;
-    };
-#pragma unroll
-    for (int i = 0; i < NSTEP; ++i) {
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) a0[e] += xv[i][e];
-        cascade(i);
     }
-    const float mean = rintf(finish() / (float)CC);
 
-    // ---- pass 2: y = x - mean (kept), second sum
+    // torch's level-1 fold after every 16 whole steps
+    static __device__ __forceinline__ void cascade(int i, float (&a0)[EPC], float (&a1)[EPC]) {
+        if (((i + 1) & 15) == 0 && i + 1 <= (NSTEP & ~15)) {
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) { a0[e] = 0.f; a1[e] = 0.f; }
-#pragma unroll
-    for (int i = 0; i < NSTEP; ++i) {
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-            const float y = xv[i][e] - mean;
-            xv[i][e] = y;
-            if (!(LNR_ABLATE & 2)) a0[e] += y * y;
+            for (int e = 0; e < EPC; ++e) { a1[e] += a0[e]; a0[e] = 0.f; }
         }
-        cascade(i);
     }
-    const float var = finish();
-    // integer Newton iteration; k' == k is a fixed point of the remaining steps, so the early exit is exact
-    float kk = 65536.0f;
-    for (int n = 0; n < ((LNR_ABLATE & 4) ? 0 : 10); ++n) {
-        const float kn = floorf((kk + floorf(var / kk)) * 0.5f);
-        const bool same = (kn == kk);
-        kk = kn;
-        if (__all(same)) break;
-    }
-    const float F = floorf((1.0f / kk) * 2147483648.0f);
-    const float Fh = F * 0.5f;       // fl(fl(y * F) * 0.5) == fl(y * (F * 0.5)): the power of two commutes with the rounding
 
-    // ---- pass 3: normalise, requotient by the channel scale, 8-bit requant, store
-    int8_t *op = out + row * CC + 8 * k + EPC * hh;
-    auto pass3 = [&](auto fast) {
+    // cb0 = 8 k + EPC h: this lane's first channel of every 32-element step; op = out + row * CC + cb0
+    static __device__ __forceinline__ void run(float (&xv)[NSTEP][EPC], int j, int k, int cb0, bool fastrq, bool live,
+                                               const double *cC, const float *cB, const float *cSc, const float *cY,
+                                               const float *bias_int, const float *sc, const ivit_dyadic *dy, int8_t *op) {
+        // ---- first sum
+        float a0[EPC], a1[EPC];
 #pragma unroll
-    for (int i = 0; i < NSTEP; ++i) {
-        const int cb = 32 * i + 8 * k + EPC * hh;
-        float bi[EPC], scv[EPC], yv[EPC];
-        double cv[EPC];
+        for (int e = 0; e < EPC; ++e) { a0[e] = 0.f; a1[e] = 0.f; }
 #pragma unroll
-        for (int e4 = 0; e4 < EPC; e4 += (EPC >= 4 ? 4 : 2)) {
-            if constexpr (EPC >= 4) {
+        for (int i = 0; i < NSTEP; ++i) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) a0[e] += xv[i][e];
+            cascade(i, a0, a1);
+        }
+        const float mean = rintf(finish(a0, a1, j, k) / (float)CC);
+
+        // ---- pass 2: y = x - mean (kept), second sum
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { a0[e] = 0.f; a1[e] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < NSTEP; ++i) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const float y = xv[i][e] - mean;
+                xv[i][e] = y;
+                if (!(LNR_ABLATE & 2)) a0[e] += y * y;
+            }
+            cascade(i, a0, a1);
+        }
+        const float var = finish(a0, a1, j, k);
+        // integer Newton iteration; k' == k is a fixed point of the remaining steps, so the early exit is exact
+        float kk = 65536.0f;
+        for (int n = 0; n < ((LNR_ABLATE & 4) ? 0 : 10); ++n) {
+            const float kn = floorf((kk + floorf(var / kk)) * 0.5f);
+            const bool same = (kn == kk);
+            kk = kn;
+            if (__all(same)) break;
+        }
+        const float F = floorf((1.0f / kk) * 2147483648.0f);
+        const float Fh = F * 0.5f;       // fl(fl(y * F) * 0.5) == fl(y * (F * 0.5)): the power of two commutes with the rounding
+
+        // ---- pass 3: normalise, requotient by the channel scale, 8-bit requant, store
+        auto pass3 = [&](auto fast) {
+#pragma unroll
+        for (int i = 0; i < NSTEP; ++i) {
+            const int cb = 32 * i + cb0;
+            float bi[EPC], scv[EPC], yv[EPC];
+            double cv[EPC];
+#pragma unroll
+            for (int e4 = 0; e4 < EPC; e4 += (EPC >= 4 ? 4 : 2)) {
+                if constexpr (EPC >= 4) {
 #if LNR_S1_VARIANT == 3
-                v4f b4 = *reinterpret_cast<const v4f *>(bias_int + cb + e4), s4 = *reinterpret_cast<const v4f *>(sc + cb + e4), y4;
-                for (int e = 0; e < 4; ++e) y4[e] = rcp_rn(s4[e]);
+                    v4f b4 = *reinterpret_cast<const v4f *>(bias_int + cb + e4), s4 = *reinterpret_cast<const v4f *>(sc + cb + e4), y4;
+                    for (int e = 0; e < 4; ++e) y4[e] = rcp_rn(s4[e]);
 #else
-                const v4f b4 = *reinterpret_cast<const v4f *>(cB + cb + e4), s4 = *reinterpret_cast<const v4f *>(cSc + cb + e4),
-                          y4 = *reinterpret_cast<const v4f *>(cY + cb + e4);
+                    const v4f b4 = *reinterpret_cast<const v4f *>(cB + cb + e4), s4 = *reinterpret_cast<const v4f *>(cSc + cb + e4),
+                              y4 = *reinterpret_cast<const v4f *>(cY + cb + e4);
 #endif
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { bi[e4 + e] = b4[e]; scv[e4 + e] = s4[e]; yv[e4 + e] = y4[e]; }
+                    for (int e = 0; e < 4; ++e) { bi[e4 + e] = b4[e]; scv[e4 + e] = s4[e]; yv[e4 + e] = y4[e]; }
+                } else {
+                    bi[0] = cB[cb]; bi[1] = cB[cb + 1]; scv[0] = cSc[cb]; scv[1] = cSc[cb + 1]; yv[0] = cY[cb]; yv[1] = cY[cb + 1];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < EPC; e += 2) {
+                typedef double v2d __attribute__((ext_vector_type(2)));
+#if LNR_S1_VARIANT == 3
+                cv[e] = dy[cb + e].m * dy[cb + e].r; cv[e + 1] = dy[cb + e + 1].m * dy[cb + e + 1].r;
+#else
+                const v2d c2 = *reinterpret_cast<const v2d *>(cC + cb + e);
+                cv[e] = c2[0]; cv[e + 1] = c2[1];
+#endif
+            }
+            unsigned pk[2] = {0, 0};
+            if constexpr (decltype(fast)::value) {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const float o = floorf(xv[i][e] * Fh) + bi[e];
+                    if (LNR_ABLATE & 1) { pk[e >> 2] |= ((unsigned)__float_as_int(o) & 0xffu) << (8 * (e & 3)); continue; }
+                    const float zz = rintf(requotient_m(o, scv[e], yv[e]));
+                    const int v = __double2loint((double)zz * cv[e] + (6755399441055744.0 + 128.0));
+                    pk[e >> 2] |= (unsigned)min(max(v, 0), 255) << (8 * (e & 3));
+                }
+                pk[0] ^= 0x80808080u; pk[1] ^= 0x80808080u;
             } else {
-                bi[0] = cB[cb]; bi[1] = cB[cb + 1]; scv[0] = cSc[cb]; scv[1] = cSc[cb + 1]; yv[0] = cY[cb]; yv[1] = cY[cb + 1];
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const float o = floorf(xv[i][e] * Fh) + bi[e];
+                    const float zz = rintf(requotient_m(o, scv[e], yv[e]));
+                    const int v = rq_c((double)zz, cv[e], -128, 127);
+                    pk[e >> 2] |= ((unsigned)v & 0xffu) << (8 * (e & 3));
+                }
+            }
+            if (live) {
+                if constexpr (EPC == 8) *reinterpret_cast<v2i *>(op + 32 * i) = v2i{(int)pk[0], (int)pk[1]};
+                else if constexpr (EPC == 4) *reinterpret_cast<unsigned *>(op + 32 * i) = pk[0];
+                else *reinterpret_cast<unsigned short *>(op + 32 * i) = (unsigned short)pk[0];
             }
         }
-#pragma unroll
-        for (int e = 0; e < EPC; e += 2) {
-            typedef double v2d __attribute__((ext_vector_type(2)));
-#if LNR_S1_VARIANT == 3
-            cv[e] = dy[cb + e].m * dy[cb + e].r; cv[e + 1] = dy[cb + e + 1].m * dy[cb + e + 1].r;
-#else
-            const v2d c2 = *reinterpret_cast<const v2d *>(cC + cb + e);
-            cv[e] = c2[0]; cv[e + 1] = c2[1];
-#endif
-        }
-        unsigned pk[2] = {0, 0};
-        if constexpr (decltype(fast)::value) {
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) {
-                const float o = floorf(xv[i][e] * Fh) + bi[e];
-                if (LNR_ABLATE & 1) { pk[e >> 2] |= ((unsigned)__float_as_int(o) & 0xffu) << (8 * (e & 3)); continue; }
-                const float zz = rintf(requotient_m(o, scv[e], yv[e]));
-                const int v = __double2loint((double)zz * cv[e] + (6755399441055744.0 + 128.0));
-                pk[e >> 2] |= (unsigned)min(max(v, 0), 255) << (8 * (e & 3));
-            }
-            pk[0] ^= 0x80808080u; pk[1] ^= 0x80808080u;
-        } else {
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) {
-                const float o = floorf(xv[i][e] * Fh) + bi[e];
-                const float zz = rintf(requotient_m(o, scv[e], yv[e]));
-                const int v = rq_c((double)zz, cv[e], -128, 127);
-                pk[e >> 2] |= ((unsigned)v & 0xffu) << (8 * (e & 3));
-            }
-        }
-        if (live) {
-            if constexpr (EPC == 8) *reinterpret_cast<v2i *>(op + 32 * i) = v2i{(int)pk[0], (int)pk[1]};
-            else if constexpr (EPC == 4) *reinterpret_cast<unsigned *>(op + 32 * i) = pk[0];
-            else *reinterpret_cast<unsigned short *>(op + 32 * i) = (unsigned short)pk[0];
-        }
+        };
+        // one branch around the whole pass (left inside, both forms are evaluated per element and selected)
+        if (fastrq) pass3(std::true_type{});
+        else pass3(std::false_type{});
     }
-    };
-    // one branch around the whole pass (left inside, both forms are evaluated per element and selected)
-    if (fastrq) pass3(std::true_type{});
-    else pass3(std::false_type{});
+};
+
+// per-channel constants of one LayerNorm -> the block's LDS copy; returns whether every channel admits the two-operation
+// 8-bit requant.  The requant rne(fl64(z * c)) is taken as the low dword of fl64(z * c) + (1.5 * 2^52 + 128) — the same two
+// roundings as the reference (quant_utils.py:229-231) in two fp64 operations instead of four, biased to 0..255 so the four
+// bytes of a dword pack without masks.  That needs |z * c| < 2^31: |y| <= 2^16 and k >= 2^16 / 2^10 after ten halvings at most
+// bound |o| by 2^40 + |bias|; a block with a channel where that bound fails keeps v_rndne_f64 + the saturating v_cvt_i32_f64.
+template <int CC, int THREADS>
+__device__ __forceinline__ bool ln_stage_constants(const float *__restrict__ bias_int, const float *__restrict__ sc,
+                                                   const ivit_dyadic *__restrict__ dy, double *cC, float *cB, float *cSc, float *cY) {
+    bool wide = false;
+    for (int c = threadIdx.x; c < CC; c += THREADS) {
+        const float scv = sc[c], bv = bias_int[c];
+        const double cv = dy[c].m * dy[c].r;
+        cSc[c] = scv;
+        cY[c] = rcp_rn(scv);
+        cB[c] = bv;
+        cC[c] = cv;
+        wide |= !(fabs(cv) * (1.2e12 + 1.01 * fabs((double)bv)) < 2147483000.0);
+    }
+    return !__syncthreads_or(wide);
+}
+
+template <int EPC>
+struct LnRaw;
+template <> struct LnRaw<8> { typedef short T __attribute__((ext_vector_type(8))); };
+template <> struct LnRaw<4> { typedef short T __attribute__((ext_vector_type(4))); };
+template <> struct LnRaw<2> { typedef short T __attribute__((ext_vector_type(2))); };
+
+template <int CC, int S>
+__global__ __launch_bounds__(LNR_THREADS(S), LNR_MIN_WAVES(CC, S)) void layernorm_reg_kernel(const int16_t *__restrict__ x, long long rows,
+                                                                     long long row_stride, float s,
+                                                                     const float *__restrict__ bias_int,
+                                                                     const float *__restrict__ sc,
+                                                                     const ivit_dyadic *__restrict__ dy,
+                                                                     int8_t *__restrict__ out) {
+#if !IVIT_PROBE_LN192_S1
+    static_assert(S != 1, "the 4-lanes-per-row form is a probe (see the note above)");
+#endif
+    typedef LnGroup<CC, S> G;
+    constexpr int LPR = G::LPR, EPC = G::EPC, NSTEP = G::NSTEP, RPW = G::RPW, RPB = (LNR_THREADS(S) / 64) * RPW;
+    __shared__ __attribute__((aligned(16))) double cC[CC];
+    __shared__ __attribute__((aligned(16))) float cB[CC], cSc[CC], cY[CC];
+    const int tid = threadIdx.x;
+    const bool fastrq = ln_stage_constants<CC, LNR_THREADS(S)>(bias_int, sc, dy, cC, cB, cSc, cY);
+    const int lane = tid & 63, j = lane % LPR, k = j / S, hh = j % S;
+    const long long row_raw = (long long)blockIdx.x * RPB + (tid >> 6) * RPW + lane / LPR;
+    const bool live = row_raw < rows;
+    const long long row = live ? row_raw : rows - 1;          // a dead lane group recomputes the last row, stores nothing
+    const int16_t *xp = x + row * row_stride + 8 * k + EPC * hh;
+    const float ys = rcp_rn(s);
+
+    // ---- load, x = fl(fl(Q*s)/s)
+    float xv[NSTEP][EPC];
+#pragma unroll
+    for (int i = 0; i < NSTEP; ++i) {
+        const typename LnRaw<EPC>::T t = *reinterpret_cast<const typename LnRaw<EPC>::T *>(xp + 32 * i);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) xv[i][e] = requotient_m((float)t[e], s, ys);
+    }
+    G::run(xv, j, k, 8 * k + EPC * hh, fastrq, live, cC, cB, cSc, cY, bias_int, sc, dy, out + row * CC + 8 * k + EPC * hh);
 }
 
 // diagnostics: requotient_m against the IEEE sequence fl(fl(q*d)/d), element-wise

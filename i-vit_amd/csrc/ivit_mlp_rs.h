@@ -101,7 +101,9 @@ __device__ __forceinline__ void rs_signal(unsigned flag_addr) {            // la
     asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_add_u32 %1, %2\n\ts_mov_b64 exec, %0"
                  : "=&s"(save) : "v"(flag_addr), "v"(1u) : "memory");
 }
-// spin until the LDS counter reaches `target` (the counters only grow).  A hand-over that never comes is a bug: trap loudly
+// spin until the LDS counter reaches `target` (the counters only grow).  A hand-over that never comes is a bug: trap loudly —
+// after 2^28 polls of >= 64 cycles each (~10 s: far beyond any stall a debugger, a profiler or throttled clocks produce, short
+// enough that a real deadlock ends the launch instead of wedging the queue)
 __device__ __forceinline__ void rs_wait(unsigned flag_addr, unsigned target) {
     unsigned v, cnt, tmp;
     asm volatile("s_mov_b32 %1, 0\n"
@@ -114,7 +116,7 @@ __device__ __forceinline__ void rs_wait(unsigned flag_addr, unsigned target) {
                  "s_cbranch_scc1 .Lrsd%=\n\t"
                  "s_sleep 1\n\t"
                  "s_add_u32 %1, %1, 1\n\t"
-                 "s_cmp_lt_u32 %1, 0x200000\n\t"
+                 "s_cmp_lt_u32 %1, 0x10000000\n\t"
                  "s_cbranch_scc1 .Lrsw%=\n\t"
                  "s_trap 2\n"
                  ".Lrsd%=:"
@@ -366,6 +368,12 @@ __global__ __launch_bounds__(RS_THREADS, 2) void mlp384rs_kernel(MlpArgs p) {
                     }
                 }
             }
+        // the producers fold maxima into all 32 NT rows of the unit, the rows >= nvalid from stale LDS; the sweep above only reads
+        // and resets the valid ones.  Reset the rest of this half-wave's slots too, so that a short unit could never hand stale
+        // maxima to a larger unit after it (the host only makes short LAST units today)
+#pragma unroll
+        for (int i = 0; i < NTK; ++i)
+            if (i * NHW >= nvalid && l32 == 0) *(lds_i32 *)(size_t)(maxa + i * NHW * 4) = (int)0x80000000;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         rs_signal(fl + 4 * RS_F_G);
     };

@@ -770,7 +770,7 @@ __global__ __launch_bounds__(MF_THREADS) void swin_mlp_fused_kernel(MlpFusedArgs
                 int o[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    o[e] = min(max((int)__builtin_rint((double)acc[g * 4 + e] * sC1[n0 + e]), -128), 127);
+                    o[e] = min(max(rint_sat_i32((double)acc[g * 4 + e] * sC1[n0 + e]), -128), 127);
                     mx = max(mx, o[e]);
                 }
                 unsigned w01 = __builtin_amdgcn_perm((unsigned)o[1], (unsigned)o[0], 0x0c0c0400u);
@@ -826,7 +826,7 @@ __global__ __launch_bounds__(MF_THREADS) void swin_mlp_fused_kernel(MlpFusedArgs
                 int o[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    o[e] = min(max((int)__builtin_rint((double)acc[g * 4 + e] * sC2[n0 + e]), -32768), 32767);
+                    o[e] = min(max(rint_sat_i32((double)acc[g * 4 + e] * sC2[n0 + e]), -32768), 32767);
                 W[g][0] = __builtin_amdgcn_perm((unsigned)o[1], (unsigned)o[0], 0x05040100u);
                 W[g][1] = __builtin_amdgcn_perm((unsigned)o[3], (unsigned)o[2], 0x05040100u);
             }
@@ -844,8 +844,8 @@ __global__ __launch_bounds__(MF_THREADS) void swin_mlp_fused_kernel(MlpFusedArgs
                     for (int w = 0; w < 4; ++w) {
                         const int t0 = (int)(short)(v[w] & 0xffff), t1 = v[w] >> 16;
                         const int r0 = (int)(short)(rs[w] & 0xffff), r1 = rs[w] >> 16;
-                        int o0 = (int)__builtin_rint((double)r0 * cr) + (int)__builtin_rint((double)t0 * cm);
-                        int o1 = (int)__builtin_rint((double)r1 * cr) + (int)__builtin_rint((double)t1 * cm);
+                        int o0 = rint_sat_i32((double)r0 * cr) + rint_sat_i32((double)t0 * cm);
+                        int o1 = rint_sat_i32((double)r1 * cr) + rint_sat_i32((double)t1 * cm);
                         o0 = min(max(o0, -32768), 32767);
                         o1 = min(max(o1, -32768), 32767);
                         v[w] = (o0 & 0xffff) | (o1 << 16);

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(SR_THREADS) void swin_mlp_rs_kernel(MlpFusedArgs p)
                             for (int f = 0; f < 2; ++f) {
                                 const double t = (double)acc[4 * q + e + f] * c2[f];
                                 o[e + f] = decltype(use_fast)::value ? __double2loint(t + (6755399441055744.0 + 128.0))
-                                                                     : min(max((int)__builtin_rint(t), -128), 127) + 128;
+                                                                     : min(max(rint_sat_i32(t), -128), 127) + 128;
                             }
                         }
                         mx = max(max(mx, o[0]), o[1]);
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(SR_THREADS) void swin_mlp_rs_kernel(MlpFusedArgs p)
 #pragma unroll
                     for (int f = 0; f < 2; ++f) {
                         const double t = (double)acc[2 * d + f] * c2[f];
-                        const int t16 = min(max(decltype(use_fast)::value ? __double2loint(t + 6755399441055744.0) : (int)__builtin_rint(t), -32768), 32767);
+                        const int t16 = min(max(decltype(use_fast)::value ? __double2loint(t + 6755399441055744.0) : rint_sat_i32(t), -32768), 32767);
                         const int r = f ? (rw >> 16) : (int)(short)(rw & 0xffff);
                         // both terms are integers < 2^31: the sum is the reference's fp64 sum (quant_utils.py:238-244)
                         o[f] = res_fast ? rq_fast(r, cr) + rq_fast(t16, cm) : rq_lean_wide(r, cr) + rq_lean_wide(t16, cm);

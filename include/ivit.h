@@ -425,7 +425,8 @@ int ivit_mlp_plan_create(ivit_handle h, ivit_linear_plan fc1, ivit_linear_plan f
 int ivit_mlp_plan_destroy(ivit_mlp_plan p);
 /* Tuning / test switch: which of the plan's two kernels ivit_mlp_fused_planned launches.  0 = by shape (the default:
  * the role-split kernel of csrc/ivit_mlp_rs.h from two 80-token units per CU on, the lock-step kernel of csrc/ivit_mlp.h
- * below that), 1 = lock-step, 2 = role-split.  Both compute the same integers (layers_quant.py:144-153).            */
+ * below that), 1 = lock-step, 2 = role-split.  Both compute the same integers (layers_quant.py:144-153).  NOT safe to call
+ * while another thread or stream is inside ivit_mlp_fused_planned on the same plan: it rewrites a field the launch reads.  */
 int ivit_mlp_plan_select(ivit_mlp_plan p, int kernel);
 int ivit_mlp_fused_planned(ivit_handle h, ivit_mlp_plan p, const int8_t *x, const int8_t *gelu_table,
                            ivit_dyadic dy_main, ivit_dyadic dy_res, const int16_t *residual, int16_t *out,

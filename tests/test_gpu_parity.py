@@ -562,12 +562,12 @@ def test_swin_engine_golden_logits(fname):
     assert np.array_equal(eng_t.forward_ops(dev(imgs)).cpu().numpy(), g["logits_int"])
 
 
-@pytest.mark.parametrize("M", [80 * 256 - 1, 80 * 256 + 1, 25216])
-def test_mlp_fused_planned_vs_oracle_production_geometry(M):
-    """the dominant kernel against the ORACLE (oracle/ivit_twin.c chains the restated operators:
-    layers_quant.py:144-153 + vit_quant.py:141-142), not against the HIP chain, at the row counts the headline run
-    produces: 25216 (a half-batch slice of DeiT-S b256) and 80 * 256 -+ 1 (one 5-tile unit per workgroup, one row short /
-    one row over: 4- and 5-tile units, clamped rows, the balanced and the round-robin schedule)."""
+@pytest.fixture(scope="module")
+def mlp_production_case():
+    """Operands of one fused Mlp (384 -> 1536 -> 384) over 50432 tokens and the ORACLE's output for them
+    (oracle/ivit_twin.c chains the restated operators: layers_quant.py:144-153 + vit_quant.py:141-142).  The operator is
+    row-wise, so the oracle's first M rows are the oracle's answer for the first M rows alone: one 50432-row CPU run (~20 s on
+    the GPU box's host) serves every row count below."""
     import os
     import subprocess
     from conftest import ROOT
@@ -578,44 +578,66 @@ def test_mlp_fused_planned_vs_oracle_production_geometry(M):
     for name in ("linear_plan_create", "mlp_plan_create", "mlp_fused_planned", "shiftgelu_build_table", "mlp_plan_destroy", "linear_plan_destroy"):
         getattr(twin, "ivit_cpu_" + name).argtypes = _lib.SIGNATURES.get("ivit_" + name, [_P])     # the destroy calls take the plan only
         getattr(twin, "ivit_cpu_" + name).restype = ctypes.c_int
+    M = 50432
     rng = np.random.default_rng(M)
     C, Hd = 384, 1536
-    x = rng.integers(-128, 128, (M, C), dtype=np.int8)
-    w1 = np.rint(rng.normal(0, 40, (Hd, C)).clip(-127, 127)).astype(np.int8); b1 = rng.integers(-2000, 2000, Hd).astype(np.int32)
-    w2 = np.rint(rng.normal(0, 40, (C, Hd)).clip(-127, 127)).astype(np.int8); b2 = rng.integers(-2000, 2000, C).astype(np.int32)
-    d1 = iv.freeze.dyadic((10 ** rng.uniform(-5.6, -5.3, Hd)).astype(np.float32), np.float32(0.04))
-    d2 = iv.freeze.dyadic((10 ** rng.uniform(-5.9, -5.6, C)).astype(np.float32), np.float32(2e-4))
-    dm, dr = iv.freeze.dyadic(np.float32(2e-4), np.float32(2.5e-4)), iv.freeze.dyadic(np.float32(3e-4), np.float32(2.5e-4))
-    res = rng.integers(-20000, 20000, (M, C)).astype(np.int16)
-    dg = iv.freeze.dyadic(np.float32(0.04 * 2.0 ** -7), np.float32(0.03))
+    c = dict(M=M, C=C, Hd=Hd, dyv=dyv)
+    c["x"] = rng.integers(-128, 128, (M, C), dtype=np.int8)
+    c["w1"] = np.rint(rng.normal(0, 40, (Hd, C)).clip(-127, 127)).astype(np.int8); c["b1"] = rng.integers(-2000, 2000, Hd).astype(np.int32)
+    c["w2"] = np.rint(rng.normal(0, 40, (C, Hd)).clip(-127, 127)).astype(np.int8); c["b2"] = rng.integers(-2000, 2000, C).astype(np.int32)
+    c["d1"] = iv.freeze.dyadic((10 ** rng.uniform(-5.6, -5.3, Hd)).astype(np.float32), np.float32(0.04))
+    c["d2"] = iv.freeze.dyadic((10 ** rng.uniform(-5.9, -5.6, C)).astype(np.float32), np.float32(2e-4))
+    c["dm"], c["dr"] = iv.freeze.dyadic(np.float32(2e-4), np.float32(2.5e-4)), iv.freeze.dyadic(np.float32(3e-4), np.float32(2.5e-4))
+    c["res"] = rng.integers(-20000, 20000, (M, C)).astype(np.int16)
+    c["dg"] = iv.freeze.dyadic(np.float32(0.04 * 2.0 ** -7), np.float32(0.03))
     tab = np.zeros(65536, np.int8)
-    assert twin.ivit_cpu_shiftgelu_build_table(None, 0.04, dyv(dg), hp(tab)) == 0
+    assert twin.ivit_cpu_shiftgelu_build_table(None, 0.04, dyv(c["dg"]), hp(tab)) == 0
+    c1, c2, cm = (_P() for _ in range(3))
+    assert twin.ivit_cpu_linear_plan_create(None, hp(c["w1"]), hp(c["b1"]), hp(c["d1"]), Hd, C, ctypes.byref(c1)) == 0
+    assert twin.ivit_cpu_linear_plan_create(None, hp(c["w2"]), hp(c["b2"]), hp(c["d2"]), C, Hd, ctypes.byref(c2)) == 0
+    assert twin.ivit_cpu_mlp_plan_create(None, c1, c2, ctypes.byref(cm)) == 0
+    oc = np.zeros((M, C), np.int16)
+    assert twin.ivit_cpu_mlp_fused_planned(None, cm, hp(c["x"]), hp(tab), dyv(c["dm"]), dyv(c["dr"]), hp(c["res"]), hp(oc), M) == 0
+    twin.ivit_cpu_mlp_plan_destroy(cm)
+    for pl in (c1, c2):
+        twin.ivit_cpu_linear_plan_destroy(pl)
+    c["oracle"] = oc
+    return c
+
+
+@pytest.mark.parametrize("M", [80 * 256 - 1, 80 * 256 + 1, 25216, 40961, 50176, 50432])
+def test_mlp_fused_planned_vs_oracle_production_geometry(M, mlp_production_case):
+    """the dominant kernel against the ORACLE, not against the HIP chain, at the row counts the headline run
+    produces: 25216 (a half-batch slice of DeiT-S b256) and 80 * 256 -+ 1 (one 5-tile unit per workgroup, one row short /
+    one row over: 4- and 5-tile units, clamped rows, the balanced and the round-robin schedule).
+    Round 6: the THREE-units-per-CU geometry of the role-split kernel — 50432 (the whole
+    DeiT-S b256 batch: units of 5 / 4 / 4 tiles, a MIDDLE unit whose producers run beside the consumers of the unit before while
+    the slice counters of the unit before that are already consumed), 50176 (units of 4 / 4 / 5: the NT = 2 -> 3 switch inside
+    one workgroup) and 40961 (two 5-tile units everywhere, exactly one workgroup with a third, one-row unit).  The output buffer
+    has a guard row behind row M - 1 that must stay untouched."""
+    c = mlp_production_case
+    C, Hd, dyv = c["C"], c["Hd"], c["dyv"]
     H = _lib.Handle(0, torch.cuda.current_stream().cuda_stream)
     tabd = torch.empty(65536, dtype=torch.int8, device="cuda")
-    H.call("ivit_shiftgelu_build_table", 0.04, dyv(dg), _P(tabd.data_ptr()))
-    d = {k: torch.from_numpy(v).cuda() for k, v in dict(x=x, w1=w1, b1=b1, w2=w2, b2=b2, d1=d1, d2=d2, res=res).items()}
-    g1, g2, gm, c1, c2, cm = (_P() for _ in range(6))
+    H.call("ivit_shiftgelu_build_table", 0.04, dyv(c["dg"]), _P(tabd.data_ptr()))
+    d = {k: torch.from_numpy(np.ascontiguousarray(c[k][:M] if k in ("x", "res") else c[k])).cuda() for k in ("x", "w1", "b1", "w2", "b2", "d1", "d2", "res")}
+    g1, g2, gm = (_P() for _ in range(3))
     H.call("ivit_linear_plan_create", _P(d["w1"].data_ptr()), _P(d["b1"].data_ptr()), _P(d["d1"].data_ptr()), Hd, C, ctypes.byref(g1))
     H.call("ivit_linear_plan_create", _P(d["w2"].data_ptr()), _P(d["b2"].data_ptr()), _P(d["d2"].data_ptr()), C, Hd, ctypes.byref(g2))
     H.call("ivit_mlp_plan_create", g1, g2, ctypes.byref(gm))
-    assert twin.ivit_cpu_linear_plan_create(None, hp(w1), hp(b1), hp(d1), Hd, C, ctypes.byref(c1)) == 0
-    assert twin.ivit_cpu_linear_plan_create(None, hp(w2), hp(b2), hp(d2), C, Hd, ctypes.byref(c2)) == 0
-    assert twin.ivit_cpu_mlp_plan_create(None, c1, c2, ctypes.byref(cm)) == 0
-    oc = np.zeros((M, C), np.int16)
-    assert twin.ivit_cpu_mlp_fused_planned(None, cm, hp(x), hp(tab), dyv(dm), dyv(dr), hp(res), hp(oc), M) == 0
+    oc = c["oracle"][:M]
     # round 5: the plan owns two kernels (lock-step ivit_mlp.h, role-split ivit_mlp_rs.h); 0 = the shape-based default
     for kernel in (0, 1, 2):
         assert H.lib.ivit_mlp_plan_select(gm, kernel) == 0
-        og = torch.full((M, C), 0x5555, dtype=torch.int16, device="cuda")
-        H.call("ivit_mlp_fused_planned", gm, _P(d["x"].data_ptr()), _P(tabd.data_ptr()), dyv(dm), dyv(dr), _P(d["res"].data_ptr()), _P(og.data_ptr()), M)
+        og = torch.full((M + 1, C), 0x5555, dtype=torch.int16, device="cuda")
+        H.call("ivit_mlp_fused_planned", gm, _P(d["x"].data_ptr()), _P(tabd.data_ptr()), dyv(c["dm"]), dyv(c["dr"]), _P(d["res"].data_ptr()), _P(og.data_ptr()), M)
         got = og.cpu().numpy()
-        assert np.array_equal(got, oc), (kernel, int((got != oc).sum()))
+        assert np.array_equal(got[:M], oc), (kernel, int((got[:M] != oc).sum()))
+        assert (got[M] == 0x5555).all(), (kernel, "wrote behind the last row")
     assert H.lib.ivit_mlp_plan_select(gm, 3) == 1 and H.lib.ivit_mlp_plan_select(None, 0) == 1
-    H.lib.ivit_mlp_plan_destroy(gm); twin.ivit_cpu_mlp_plan_destroy(cm)
+    H.lib.ivit_mlp_plan_destroy(gm)
     for pl in (g1, g2):
         H.lib.ivit_linear_plan_destroy(pl)
-    for pl in (c1, c2):
-        twin.ivit_cpu_linear_plan_destroy(pl)
 
 
 # ---------------------------------------------------------------- calibration (SURVEY §8f N1)
@@ -746,6 +768,18 @@ def test_full_size_batch_properties_deit_small_b256():
     out = rep()
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy(), ref)
+    _oracle_sample_check(cfg, w, golden_scales(g), imgs, ref, 32, first_free=4)
+
+
+def _oracle_sample_check(cfg, w, scales, imgs, ref, count, first_free, swin=False):
+    """a random sample of NON-golden images of a full-size batch against the CPU oracle
+    (oracle/ivit_oracle.c through OracleViT / OracleSwin, ~6 DeiT-S images per second on the GPU box's host) — the
+    properties above only ever compare those images with the HIP path itself."""
+    from oracle import oracle as orc
+    idx = np.sort(np.random.default_rng(2026).choice(np.arange(first_free, len(imgs)), size=count, replace=False))
+    o = (orc.OracleSwin if swin else orc.OracleViT)(cfg, w, scales)
+    want, _ = o.forward(np.ascontiguousarray(imgs[idx]))
+    assert np.array_equal(ref[idx], np.asarray(want)), "HIP logits of sampled batch images differ from the oracle"
 
 
 def test_full_size_batch_properties_swin_tiny_b64():
@@ -1337,6 +1371,8 @@ def test_full_size_batch_properties_vit_configs(fname, B):
     out = rep()
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy(), ref)
+    # DeiT-B: 32 of the 60 non-golden, non-duplicate images; ViT-B@384 (13x the work per image): 8
+    _oracle_sample_check(cfg, w, golden_scales(g), imgs[:B - gb], ref, 32 if B == 64 else 8, first_free=gb)
 
 
 def test_full_size_batch_properties_swin_tiny_b256():
@@ -1359,6 +1395,7 @@ def test_full_size_batch_properties_swin_tiny_b256():
     out = rep()
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy(), ref)
+    _oracle_sample_check(cfg, iv.make_swin_weights(cfg, int(g["seed"])), golden_scales(g), imgs[:255], ref, 8, first_free=1, swin=True)
 
 
 def test_model_zoo_vit_large_golden():
@@ -1605,3 +1642,52 @@ def test_layernorm_beside_gemms_concurrency(H):
                 assert torch.equal(outs[i][k], refs[k]), (rep, i, k)
     for h in hs:
         h.close()
+
+
+# ---------------------------------------------------------------- the multi-rank paths on ONE GPU
+def _run_ranks(args, env_extra, timeout):
+    import os
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, IVIT_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), **env_extra)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port)] + args
+    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py's `world > 1` branch (broadcast of the constants blob, the barriers, the MAX all-reduce over ranks, the
+    every-rank exit) had never executed on a GPU: run it as the driver launches it — torch.distributed.run, 2 ranks — with both
+    ranks on device 0 and gloo as the transport (bench.py: IVIT_DIST_BACKEND, `local_rank % device_count`).  Then the same
+    with a deliberately wrong golden: BOTH ranks must leave non-zero, promptly, and print no JSON line."""
+    import json
+    import time
+    args = ["bench.py", "--gpus", "2", "--model", "deit_tiny", "--batch", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+            "--profile-steps", "0", "--min-seconds", "0", "--reps", "1"]
+    r = _run_ranks(args, {}, 300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                      # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 16 and out["scaling"] == "weak"
+    assert out["bit_exact_vs_reference_golden"] is True and out["all_images_equal_unsliced_forward"] is True
+    assert out["value"] > 0 and abs(out["value"] - 16 * out["steps"] / (out["ms_per_step"] * 1e-3 * out["steps"])) < 1e-3 * out["value"]
+    t0 = time.time()
+    bad = _run_ranks(args, {"IVIT_BENCH_SELFTEST_WRONG_GOLDEN": "1"}, 300)
+    assert bad.returncode != 0 and time.time() - t0 < 120
+    assert not [ln for ln in bad.stdout.splitlines() if ln.startswith("{")], "a wrong golden prefix must not produce a bench line"
+    assert "golden prefix differ" in bad.stderr
+
+
+def test_engine_forward_sharded_over_two_ranks():
+    """SURVEY §4 multi-GPU row ("on 1 GPU simulate N shards") through the HIP ENGINE, not the oracle: two ranks receive the
+    broadcast constants, each runs the native forward on its shard of 7 images (ragged: 4 + 3), the gathered logits equal
+    the unsharded forward and the golden prefix (tools/dist_shard_check.py)."""
+    r = _run_ranks(["tools/dist_shard_check.py", "micro_vit2h_b3.npz", "7"], {}, 300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "SHARD_CHECK_OK world 2 shards [(0, 4), (4, 7)]" in r.stdout

@@ -59,6 +59,28 @@ __global__ void k_pkadd(float *out, int n) {
     for (int k = 0; k < 8; ++k) s += a[k][0] + a[k][1];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
+__global__ void k_pkmul(float *out, int n) {
+    v2f a[8];
+    for (int k = 0; k < 8; ++k) a[k] = v2f{1.0f + threadIdx.x * 1e-3f + k, 0.5f + k};
+    for (int i = 0; i < n; ++i) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) asm volatile("v_pk_mul_f32 %0, %0, %0" : "+v"(a[k]));
+    }
+    float s = 0;
+    for (int k = 0; k < 8; ++k) s += a[k][0] + a[k][1];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ void k_f32add(float *out, int n) {
+    float a[8];
+    for (int k = 0; k < 8; ++k) a[k] = 1.0f + threadIdx.x + k;
+    for (int i = 0; i < n; ++i) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) asm volatile("v_add_f32 %0, %0, %0" : "+v"(a[k]));
+    }
+    float s = 0;
+    for (int k = 0; k < 8; ++k) s += a[k];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
 __global__ void k_ldsgather(float *out, int n) {   // dependent-free random ds_read_b32 over a 1 KB table
     __shared__ float tbl[256];
     tbl[threadIdx.x & 255] = threadIdx.x;
@@ -129,6 +151,8 @@ int main() {
     run("cvt64 pair", k_cvt64, (double *)buf, 16);
     run("pk_fma_f32", k_pkfma, (float *)buf, 8);
     run("pk_add_f32", k_pkadd, (float *)buf, 8);
+    run("pk_mul_f32", k_pkmul, (float *)buf, 8);
+    run("f32 add", k_f32add, (float *)buf, 8);
     run("lds gather(+2 valu)", k_ldsgather, (float *)buf, 8);
     return 0;
 }
