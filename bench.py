@@ -249,6 +249,8 @@ def main():
     ap.add_argument("--streams", type=int, default=int(os.environ.get("IVIT_STREAMS", "0")),
                     help="batch slices on the runner's internal HIP streams (0 = per-model default)")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("IVIT_GRAPH", "1")), help="replay a captured hipGraph")
+    ap.add_argument("--auto-mode", type=int, default=1,
+                    help="unless --streams / --graph are given: try (default slices + hipGraph) and (one stream, eager) untimed, time the faster")
     args = ap.parse_args()
 
     world_env = os.environ.get("WORLD_SIZE")
@@ -317,10 +319,30 @@ def main():
                 dist.destroy_process_group()
             raise SystemExit(msg)
 
-    if args.graph:
-        step = eng.capture(imgs, streams)
-    else:
-        step = lambda: eng.forward(imgs, nslices=streams)
+    def make_step(nstreams, graph):
+        return eng.capture(imgs, nstreams) if graph else (lambda: eng.forward(imgs, nslices=nstreams))
+
+    # Launch mode.  Two ways of issuing the SAME forward: `streams` batch slices on the runner's internal streams replayed as
+    # one hipGraph, or the whole batch eagerly on one stream (shorter kernel boundaries, full-batch kernel geometry).  Which one
+    # is faster differs by box (+-1.5 %, profiles/README.md round 6), so unless --streams / --graph pin it, both are tried for a
+    # few untimed steps and the faster one is the mode of the warm-up and of the timed region; the choice is reported.
+    mode_trials = None
+    pinned = any(a.split("=")[0] in ("--streams", "--graph") for a in sys.argv[1:]) or "IVIT_STREAMS" in os.environ or "IVIT_GRAPH" in os.environ
+    if args.auto_mode and not pinned and batch > 1:
+        mode_trials = []
+        for ns, gr in ((streams, 1), (1, 0)):
+            st = make_step(ns, gr)
+            for _ in range(3):
+                st()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                st()
+            torch.cuda.synchronize()
+            mode_trials.append({"streams": ns, "hipgraph": bool(gr), "ms_per_step": round((time.perf_counter() - t0) / 10 * 1e3, 4)})
+        best = min(mode_trials, key=lambda m: m["ms_per_step"])
+        streams, args.graph = best["streams"], int(best["hipgraph"])
+    step = make_step(streams, args.graph)
     # every image of the timed mode (slices on internal streams, hipGraph) against ONE unsliced forward on the current stream,
     # five times, before anything is timed: a race between slices shows up in some image of some run, never reliably in the
     # golden prefix checked below
@@ -397,11 +419,17 @@ def main():
             hbm_ops["shiftgelu_requant"] = hbm("ivit_shiftgelu_requant_lut", cfg.depth * M * Hd * 2)
             # fused attention is bound by NEITHER roofline (VALU / LDS chains per score): both fractions are printed, outside
             # the HBM-bound list
-            att = "ivit_attention_fused_lut" if "ivit_attention_fused_lut" in per else "ivit_attention_fused"
-            attention = hbm(att, cfg.depth * M * D * 4)
+            # (layers differ in the Shiftmax form their scale admits: row tables, two-level tables, arithmetic — one class here)
+            att_names = [n for n in per if n.startswith("ivit_attention_fused")]
+            if att_names:
+                per["attention_fused (all forms)"] = [sum(per[n][0] for n in att_names), sum(per[n][1] for n in att_names)]
+            attention = hbm("attention_fused (all forms)", cfg.depth * M * D * 4)
+            per.pop("attention_fused (all forms)", None)
+            if attention is not None:
+                attention["forms"] = {n: per[n][1] // ps for n in att_names}
             if attention is not None:
                 a_tops = bmm_ops * batch / (attention["ms_per_step"] * 1e-3) / 1e12
-                attention = {"ms_per_step": attention["ms_per_step"], "launches": attention["launches"],
+                attention = {"ms_per_step": attention["ms_per_step"], "launches": attention["launches"], "forms": attention["forms"],
                              "hbm": {k: attention[k] for k in ("algorithmic_bytes_per_step", "achieved", "peak", "unit", "frac")},
                              "mfma": {"algorithmic_ops_per_step": bmm_ops * batch, "achieved": round(a_tops, 1), "peak": INT8_PEAK_TOPS,
                                       "unit": "TOP/s", "frac": round(a_tops / INT8_PEAK_TOPS, 4)},
@@ -480,7 +508,8 @@ def main():
             "config": {"workload": f"{cfg.name} int8 forward, batch {batch}/GPU, {cfg.img_size}x{cfg.img_size}x3 synthetic int8 "
                                    f"(BASELINE.json {which}); weights seeded synthetic, activation scales from the reference calibration",
                        "global_batch": batch * world, "parallelism": f"dp{world} (batch-sharded, weights RCCL-broadcast once)",
-                       "streams_per_gpu": streams, "hipgraph": bool(args.graph)},
+                       "streams_per_gpu": streams, "hipgraph": bool(args.graph),
+                       "launch_mode_trials": mode_trials},
             "repetitions_ms_per_step": [round(d / args.steps * 1e3, 4) for d in rep_dt],
             "value_is": "median repetition",
             "model_int8_tops": round((lin_ops + bmm_ops) * batch * world / (ms_per_step * 1e-3) / 1e12, 1),

@@ -197,6 +197,8 @@ SIGNATURES = {
     "ivit_attn_pv_requant": [_P, _P, _P, Dyadic, _P, _I, _I, _I, _I, _I, _I],
     "ivit_attention_fused": [_P, _P, _P, _P, Dyadic, _F, Dyadic, _P, _I, _I, _I, _I, _I],
     "ivit_attention_fused_lut": [_P, _P, _P, _P, Dyadic, _F, _P, _P, _P, _I, _I, _I, Dyadic, _P, _I, _I, _I, _I, _I],
+    "ivit_shiftmax_rowtable": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "ivit_attention_fused_rowlut": [_P, _P, _P, _P, Dyadic, _F, _P, _I, Dyadic, _P, _I, _I, _I, _I, _I],
     "ivit_requant_i32": [_P, _P, _P, _I, _P, _P, _I, _P, _L, _I],
     "ivit_requant_f32": [_P, _P, _P, _I, _P, _P, _I, _P, _L, _I],
     "ivit_shiftmax": [_P, _P, _L, _I, _I, _F, _I, _P, _I],

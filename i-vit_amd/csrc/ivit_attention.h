@@ -28,7 +28,16 @@ struct AttnArgs {
     const float *et;           // [t_count]
     const uint8_t *cls;        // [256] class of v
     int nc, t_count, dmin;
+    // optional ROW tables (ivit_shiftmax_rowtable): rowtab[vmax + 128][dd] = exp_int of a score v = vmax + dmin + dd in a row
+    // whose maximum is vmax, dd = max(v - vmax, dmin) - dmin in [0, 64): both table levels above folded per row maximum
+    const float *rowtab;       // [256][64]
 };
+#define ATT_HAS_ROWTAB 1
+// LDS of the row-line form: per wavefront 16 lines (one per query of the tile) of 64 entries at a pitch of 66 dwords — 8-byte
+// aligned for the ds_write_b64 that fills them, and entry dd of line i sits on bank (2 i + dd) mod 32, so the 16 rows' entry 0
+// (every score further than dmin below its row maximum reads entry 0) are 16 different banks
+#define ATT_LINE_PITCH 264
+#define ATT_ROWLINE_BYTES (ATT_WAVES * 16 * ATT_LINE_PITCH)
 
 // wavefronts per workgroup.  8 = two workgroups per CU fill the 16 wave slots that 121 registers allow (round 4, after the prologue
 // changes: 52-54 us against 60-61 with 7, which had been the better choice in round 3; 6: slower)
@@ -37,6 +46,9 @@ struct AttnArgs {
 #endif
 #ifndef ATT_PROBE          // timing probes only (results invalid): 1 first gather lane-linear, 2 second gather lane-linear with the
 #define ATT_PROBE 0        // first one dead, 4 second gather lane-linear with the first one kept alive, 8 no second gather
+#endif
+#ifndef ATT_PERMLANE       // probe: 1 = row maximum by v_permlane16/32_swap, 2 = the partner accumulators of the row sum likewise
+#define ATT_PERMLANE 2     // (instead of ds_bpermute).  Same box, interleaved twice: 1 costs +3 us (it sits on the tile's critical path), 2 gains 0.3
 #endif
 #define ATT_DH 64
 
@@ -60,12 +72,17 @@ struct AttCfg {
 // FAST: |c_qk|, |c_pv| < 2^9 (host-checked) -> rq_fast is exact.  TT: the token count when it is known at
 // compile time (197 / 577: the 224- and 384-pixel ViTs), 0 = run-time p.T.  With TT fixed every tile-validity
 // test folds away; the generic form keeps ~70 loop-invariant lane masks alive and spills SGPRs in the hot loop.
-// LUT: shift-exp by table lookup (two LDS gathers per score instead of ~20 fp32 operations); the tables follow
+// LUT = 1: shift-exp by table lookup (two LDS gathers per score instead of ~20 fp32 operations); the tables follow
 // the fixed LDS regions and are copied in once per workgroup.
+// LUT = 2 (round 6): ONE gather per score.  In a row with maximum vmax only the scores v in (vmax + dmin, vmax] have an exp_int
+// above the floor constant, so exp_int as a function of dd = max(v - vmax, dmin) - dmin is a table line of R = 1 - dmin <= 64
+// entries that depends on vmax alone: the wave fetches its 16 queries' lines (256 B each, from the 64 KB rowtab in L2) into LDS
+// once the row maxima are known and every score then costs a saturating subtract, an address and one ds_read_b32 — the
+// class-of-v gather, its address arithmetic and the per-workgroup copy of the two-level tables are gone.
 #ifndef ATT_MINW           // waves per SIMD the kernel is compiled for (probe; 1 = whatever the workgroup size implies)
 #define ATT_MINW 1
 #endif
-template <int NB, bool FAST, int TT = 0, bool LUT = false>
+template <int NB, bool FAST, int TT = 0, int LUT = 0>
 __global__ __launch_bounds__(ATT_WAVES * 64, ATT_MINW) void attn_fused_kernel(AttnArgs p) {
     using C = AttCfg<NB>;
     extern __shared__ __attribute__((aligned(16))) char dsmem[];
@@ -74,9 +91,9 @@ __global__ __launch_bounds__(ATT_WAVES * 64, ATT_MINW) void attn_fused_kernel(At
     char *sO = sV + C::SV_BYTES;
     int *sCol = reinterpret_cast<int *>(sO + C::SO_BYTES);
     float *sXq = reinterpret_cast<float *>(sO + C::SO_BYTES + 256);   // fl(fl(Q*s)/s) for Q = -128..127
-    float *sT = reinterpret_cast<float *>(dsmem + C::SMEM);           // LUT only: exp table, then aq, then cls
-    unsigned short *sAQ = reinterpret_cast<unsigned short *>(sT + (LUT ? (p.t_count + 3) & ~3 : 0));   // 16-byte aligned
-    unsigned char *sCls = reinterpret_cast<unsigned char *>(sAQ + (LUT ? p.nc * 256 : 0));
+    float *sT = reinterpret_cast<float *>(dsmem + C::SMEM);           // LUT = 1 only: exp table, then aq, then cls
+    unsigned short *sAQ = reinterpret_cast<unsigned short *>(sT + (LUT == 1 ? (p.t_count + 3) & ~3 : 0));   // 16-byte aligned
+    unsigned char *sCls = reinterpret_cast<unsigned char *>(sAQ + (LUT == 1 ? p.nc * 256 : 0));
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
@@ -96,6 +113,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, ATT_MINW) void attn_fused_kernel(At
     constexpr int NTH = ATT_WAVES * 64;
     constexpr int KI = (C::TK * 4 + NTH - 1) / NTH, VI = (64 * C::NT + NTH - 1) / NTH;
     v4i kreg[KI], vreg[VI];
+
 #pragma unroll
     for (int i = 0; i < KI; ++i) {
         const int c = tid + i * NTH, row = c >> 2, g = c & 3;
@@ -108,7 +126,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, ATT_MINW) void attn_fused_kernel(At
         vreg[i] = v4i{0, 0, 0, 0};
         if (c < 64 * C::NT && t0 < T) vreg[i] = *reinterpret_cast<const v4i *>(vg + (long long)d * p.ldv + t0);
     }
-    if (LUT && !(ATT_PROBE & 32)) {
+    if (LUT == 1 && !(ATT_PROBE & 32)) {
         // table offsets are staged as BYTE offsets into sT (x4: t_count <= 16384 keeps them in 16 bits): a score's
         // table address is then one v_lshl_add_u32 on top of the saturating distance
         const int n4 = p.t_count >> 2, a4 = p.nc * 32;          // whole 16-byte chunks (the launcher checks the alignment)
@@ -156,12 +174,17 @@ __global__ __launch_bounds__(ATT_WAVES * 64, ATT_MINW) void attn_fused_kernel(At
         }
     }
     if (tid < 256) sXq[tid] = requotient_c((float)(tid - 128), rcp_prepare(p.s_softmax));
+    if (tid < 64) sCol[tid] = 0;
     __syncthreads();
-    if (tid < 64) {  // column sums of V (per d) over all keys
+    {   // column sums of V (per d) over all keys: every wave takes 1 / ATT_WAVES of the keys of all 64 columns and adds its
+        // partial sum with one LDS atomic (round 6: one wave walking all TK / 4 words was a ~2 us serial section per workgroup)
+        static_assert((C::TK / 4) % ATT_WAVES == 0, "whole words per wave");
+        constexpr int WPP = C::TK / 4 / ATT_WAVES;
         int s = 0;
-        const int *row = reinterpret_cast<const int *>(sV + tid * C::VS);
-        for (int w = 0; w < C::TK / 4; ++w) s = __builtin_amdgcn_sdot4(row[w], 0x01010101, s, false);
-        sCol[tid] = s;
+        const int *row = reinterpret_cast<const int *>(sV + lane * C::VS) + wave * WPP;
+#pragma unroll
+        for (int w = 0; w < WPP; ++w) s = __builtin_amdgcn_sdot4(row[w], 0x01010101, s, false);
+        atomicAdd(&sCol[lane], s);
     }
     __syncthreads();
 
@@ -177,6 +200,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, ATT_MINW) void attn_fused_kernel(At
     const int nvec = T >> 3, size = nvec >> 2;
 
     if (ATT_PROBE & 16) return;           // prologue only
+    // (round 6: requesting this fragment together with the K / V^T rows of the prologue measured 0.5-1 us SLOWER on one box)
     v4i qnext = {0, 0, 0, 0};
     if (wave < nqt && wave * 16 + qi < T) qnext = *reinterpret_cast<const v4i *>(qg + (wave * 16 + qi) * 64 + g * 16);
     for (int qt = wave; qt < nqt; qt += ATT_WAVES) {
@@ -213,18 +237,62 @@ __global__ __launch_bounds__(ATT_WAVES * 64, ATT_MINW) void attn_fused_kernel(At
                 for (int r = 0; r < 4; ++r) f[j][r] = 0.f;
             }
         }
-        qmax = max(qmax, __shfl_xor(qmax, 16));
-        qmax = max(qmax, __shfl_xor(qmax, 32));
+        // the query's four lanes (qi, qi + 16, qi + 32, qi + 48): two register swaps instead of two trips through the LDS crossbar —
+        // v_permlane16_swap(a, a) leaves (rows 0 0 2 2 | rows 1 1 3 3), v_permlane32_swap(a, a) (rows 0 1 0 1 | rows 2 3 2 3)
+        if (ATT_PERMLANE & 1) {
+            auto s16 = __builtin_amdgcn_permlane16_swap((unsigned)qmax, (unsigned)qmax, false, false);
+            qmax = max((int)s16[0], (int)s16[1]);
+            auto s32 = __builtin_amdgcn_permlane32_swap((unsigned)qmax, (unsigned)qmax, false, false);
+            qmax = max((int)s32[0], (int)s32[1]);
+        } else {
+            qmax = max(qmax, __shfl_xor(qmax, 16));
+            qmax = max(qmax, __shfl_xor(qmax, 32));
+        }
         const float mx = sXq[qmax + 128 - VB];
         // byte offset of aq[class(vmax)][v' = 0]: ((class * 256 + 128) - VB) * 2
-        const int rowbase2 = LUT ? ((int)sCls[qmax + 128 - VB] * 256 + 128 - VB) * 2 : 0;
+        const int rowbase2 = LUT == 1 ? ((int)sCls[qmax + 128 - VB] * 256 + 128 - VB) * 2 : 0;
         // LDS address of this query row's table line, once per row: the first gather's address is then ONE v_lshl_add_u32 per
         // score (round 4: left to the compiler it was a shift plus a three-input add on the run-time table base, 1.4 + 1.3 per score)
         typedef __attribute__((address_space(3))) const char att_lds_c;
         const unsigned aqrow = (unsigned)(size_t)((att_lds_c *)sAQ) + (unsigned)rowbase2;
 
         // ---- shift-exp; keys >= T contribute exactly 0
-        if (LUT) {
+        if (LUT == 2) {
+            // this wave's 16 table lines: lane (qi, g) brings entries [16 g, 16 g + 16) of its query's line
+            const unsigned lines = (unsigned)C::SMEM + (unsigned)wave * (16 * ATT_LINE_PITCH);
+            {
+                const v4f *src = reinterpret_cast<const v4f *>(p.rowtab + (qmax + 128 - VB) * 64 + 16 * g);
+                v4f l[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) l[u] = src[u];
+                typedef float v2f __attribute__((ext_vector_type(2)));
+                typedef __attribute__((address_space(3))) v2f lds_v2f;
+                const unsigned dst = lines + (unsigned)qi * ATT_LINE_PITCH + (unsigned)g * 64;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    *(lds_v2f *)(size_t)(dst + u * 16) = v2f{l[u][0], l[u][1]};
+                    *(lds_v2f *)(size_t)(dst + u * 16 + 8) = v2f{l[u][2], l[u][3]};
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the lines are read by the other lanes of THIS wave only
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const unsigned qd = (unsigned)(qmax + p.dmin);      // max(v - vmax, dmin) - dmin == max(v' - qd', 0); qd' >= 1
+            const unsigned line = lines + (unsigned)qi * ATT_LINE_PITCH;
+#pragma unroll
+            for (int j = 0; j < C::NT; ++j)
+                if (j < ntile) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        unsigned a = (__builtin_elementwise_sub_sat((unsigned)__float_as_int(f[j][r]), qd) << 2) + line;
+                        asm("" : "+v"(a));                       // one v_lshl_add_u32; not re-associated with the LDS base
+                        const float e = *reinterpret_cast<__attribute__((address_space(3))) const float *>((size_t)a);
+                        f[j][r] = (j * 16 + 15 < T || j * 16 + g * 4 + r < T) ? e : 0.f;
+                    }
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the next tile's lines overwrite these
+            __builtin_amdgcn_wave_barrier();
+        } else if (LUT) {
             // two dependent LDS gathers per score, issued as two whole sweeps so the reads of a sweep are all in
             // flight together (one wait per sweep instead of one per score)
             const unsigned qd = (unsigned)(qmax + p.dmin);      // max(v - vmax, dmin) - dmin == max(v' - qd', 0); qd' >= 1
@@ -330,7 +398,16 @@ __global__ __launch_bounds__(ATT_WAVES * 64, ATT_MINW) void attn_fused_kernel(At
         float pl[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            float o0 = __shfl_xor(A0[0][r], 32), o1 = __shfl_xor(A0[1][r], 32);
+            // lane ^ 32's accumulators, needed on the lower 32 lanes only: after v_permlane32_swap(a, a) the second result holds
+            // (upper half | upper half)
+            float o0, o1;
+            if (ATT_PERMLANE & 2) {
+                o0 = __uint_as_float(__builtin_amdgcn_permlane32_swap(__float_as_uint(A0[0][r]), __float_as_uint(A0[0][r]), false, false)[1]);
+                o1 = __uint_as_float(__builtin_amdgcn_permlane32_swap(__float_as_uint(A0[1][r]), __float_as_uint(A0[1][r]), false, false)[1]);
+            } else {
+                o0 = __shfl_xor(A0[0][r], 32);
+                o1 = __shfl_xor(A0[1][r], 32);
+            }
             pl[r] = ((A0[0][r] + o0) + A0[1][r]) + o1;   // valid on lanes g = 0 (l=r) and g = 1 (l=4+r)
         }
         float fin = 0.f;

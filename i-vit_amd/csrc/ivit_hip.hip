@@ -749,9 +749,10 @@ int ivit_mlp_fused_planned(ivit_handle h, ivit_mlp_plan p, const int8_t *x, cons
 
 }  // extern "C"
 
-template <int NB, bool FAST, int TT = 0, bool LUT = false>
+template <int NB, bool FAST, int TT = 0, int LUT = 0>
 static int launch_attn2(ivit_handle h, const AttnArgs &a, int BH) {
-    const size_t lds = AttCfg<NB>::SMEM + (LUT ? (size_t)((a.t_count + 3) & ~3) * 4 + (size_t)a.nc * 512 + 256 : 0);
+    const size_t lds = AttCfg<NB>::SMEM + (LUT == 2 ? (size_t)ATT_ROWLINE_BYTES
+                                                   : (LUT == 1 ? (size_t)((a.t_count + 3) & ~3) * 4 + (size_t)a.nc * 512 + 256 : 0));
     if (lds > 65536) {
         hipError_t e = hipFuncSetAttribute((const void *)attn_fused_kernel<NB, FAST, TT, LUT>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -769,6 +770,11 @@ static int launch_attn(ivit_handle h, const AttnArgs &a, int BH) {
     const bool fast = (cq < 512.0 && cq > -512.0 && cp < 512.0 && cp > -512.0);
     constexpr bool dyn_t = (IVIT_OPT_ATTN_GENERIC & 1) != 0, no_lut = (IVIT_OPT_ATTN_GENERIC & 2) != 0;
     const bool lut = a.aq && a.et && a.cls && !no_lut;
+    if (a.rowtab) {     // row-line tables (ivit_attention_fused_rowlut): the multipliers were checked by the caller
+        if (NB == 4 && a.T == 197 && !dyn_t) return launch_attn2<NB, true, 197, 2>(h, a, BH);
+        if (NB == 10 && a.T == 577 && !dyn_t) return launch_attn2<NB, true, 577, 2>(h, a, BH);
+        return launch_attn2<NB, true, 0, 2>(h, a, BH);
+    }
     if (fast && !dyn_t) {
         if (NB == 4 && a.T == 197) return lut ? launch_attn2<NB, true, 197, true>(h, a, BH) : launch_attn2<NB, true, 197>(h, a, BH);
         if (NB == 10 && a.T == 577) return lut ? launch_attn2<NB, true, 577, true>(h, a, BH) : launch_attn2<NB, true, 577>(h, a, BH);
@@ -779,7 +785,8 @@ static int launch_attn(ivit_handle h, const AttnArgs &a, int BH) {
 
 static int attention_fused_impl(ivit_handle h, const int8_t *q, const int8_t *k, const int8_t *vt, ivit_dyadic dy_qk,
                                 float s_softmax, ivit_dyadic dy_pv, int8_t *ctx8, int B, int H, int T, int dh, int ldv,
-                                const uint16_t *aq, const float *et, const uint8_t *cls, int nc, int t_count, int dmin) {
+                                const uint16_t *aq, const float *et, const uint8_t *cls, int nc, int t_count, int dmin,
+                                const float *rowtab = nullptr) {
     CHECK_H(h);
     REQUIRE(h, q && k && vt && ctx8 && B > 0 && H > 0 && T > 0 && s_softmax > 0.f, "bad arguments");
     REQUIRE(h, (ldv % 16) == 0 && ldv >= T, "ldv must be a multiple of 16 and >= T");
@@ -794,7 +801,7 @@ static int attention_fused_impl(ivit_handle h, const int8_t *q, const int8_t *k,
     AttnArgs a;
     a.q = q; a.k = k; a.vt = vt; a.ctx = ctx8; a.T = T; a.H = H; a.ldv = ldv;
     a.s_softmax = s_softmax; a.dy_qk = dy_qk; a.dy_pv = dy_pv;
-    a.aq = aq; a.et = et; a.cls = cls; a.nc = nc; a.t_count = t_count; a.dmin = dmin;
+    a.aq = aq; a.et = et; a.cls = cls; a.nc = nc; a.t_count = t_count; a.dmin = dmin; a.rowtab = rowtab;
     if (T <= 64) return launch_attn<1>(h, a, B * H);
     if (T <= 256) return launch_attn<4>(h, a, B * H);
     return launch_attn<10>(h, a, B * H);
@@ -812,6 +819,48 @@ extern "C" int ivit_attention_fused_lut(ivit_handle h, const int8_t *q, const in
                                         int8_t *ctx8, int B, int H, int T, int dh, int ldv) {
     if (h && !(exp_aq && exp_t && exp_cls)) { snprintf(h->err, sizeof(h->err), "ivit_attention_fused_lut: null table"); return IVIT_ERR_INVALID; }
     return attention_fused_impl(h, q, k, vt, dy_qk, s_softmax, dy_pv, ctx8, B, H, T, dh, ldv, exp_aq, exp_t, exp_cls, nclass, t_count, dmin);
+}
+
+// rowtab[vmax + 128][dd] = exp_t[exp_aq[exp_cls[vmax]][v] + dd] for the score v = vmax + dmin + dd (dd = 0: every score at or
+// below vmax + dmin, the floor constant of the table whatever the class); one thread per entry
+__global__ __launch_bounds__(64) void shiftmax_rowtable_kernel(const uint16_t *__restrict__ aq, const float *__restrict__ et,
+                                                               const uint8_t *__restrict__ cls, int dmin, float *__restrict__ rowtab) {
+    const int q = blockIdx.x, dd = threadIdx.x, R = 1 - dmin;
+    int vi = q + dmin + dd;
+    float val = 0.f;
+    if (dd < R && (vi >= 0 || dd == 0)) {
+        vi = vi < 0 ? 0 : vi;
+        val = et[(int)aq[(int)cls[q] * 256 + vi] + dd];
+    }
+    rowtab[q * 64 + dd] = val;
+}
+
+extern "C" int ivit_shiftmax_rowtable(ivit_handle h, const uint16_t *exp_aq, const float *exp_t, const uint8_t *exp_cls,
+                                      int nclass, int t_count, int dmin, float *rowtab) {
+    CHECK_H(h);
+    REQUIRE(h, exp_aq && exp_t && exp_cls && rowtab && nclass >= 1 && nclass <= 64 && t_count >= 1 && t_count <= 16384 &&
+                   dmin <= 0 && dmin >= -255, "bad Shiftmax tables");
+    if (1 - dmin > 64) {
+        snprintf(h->err, sizeof(h->err), "%s: a table line holds 64 entries, this scale needs %d (use ivit_attention_fused_lut)", __func__, 1 - dmin);
+        return IVIT_ERR_UNSUPPORTED;
+    }
+    REQUIRE(h, ((uintptr_t)rowtab & 15) == 0, "rowtab must be 16-byte aligned");
+    shiftmax_rowtable_kernel<<<256, 64, 0, h->stream>>>(exp_aq, exp_t, exp_cls, dmin, rowtab);
+    LAUNCH_CHECK(h);
+    return IVIT_OK;
+}
+
+extern "C" int ivit_attention_fused_rowlut(ivit_handle h, const int8_t *q, const int8_t *k, const int8_t *vt,
+                                           ivit_dyadic dy_qk, float s_softmax, const float *rowtab, int dmin, ivit_dyadic dy_pv,
+                                           int8_t *ctx8, int B, int H, int T, int dh, int ldv) {
+    if (!h) return IVIT_ERR_INVALID;
+    REQUIRE(h, rowtab && ((uintptr_t)rowtab & 15) == 0 && dmin <= 0 && dmin >= -63, "bad row table (16-byte aligned, 1 - dmin <= 64)");
+    const double cq = dy_qk.m * dy_qk.r, cp = dy_pv.m * dy_pv.r;
+    if (!(cq < 512.0 && cq > -512.0 && cp < 512.0 && cp > -512.0)) {
+        snprintf(h->err, sizeof(h->err), "%s: requant multipliers out of the fast range (use ivit_attention_fused_lut)", __func__);
+        return IVIT_ERR_UNSUPPORTED;
+    }
+    return attention_fused_impl(h, q, k, vt, dy_qk, s_softmax, dy_pv, ctx8, B, H, T, dh, ldv, nullptr, nullptr, nullptr, 0, 0, dmin, rowtab);
 }
 
 // ---------------------------------------------------------------- requant

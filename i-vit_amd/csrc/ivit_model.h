@@ -13,6 +13,8 @@ struct ivit_vit_s {
     int T, ld, Kp, num_patches;
     bool fused_attention;
     int8_t *gelu_tab;                 // [depth][65536]
+    float *rowtab;                    // [depth][256][64] Shiftmax row tables (ivit_shiftmax_rowtable) or null
+    std::vector<char> has_rowtab;     // per block: its scale's table lines fit 64 entries and the multipliers are in the fast range
     std::vector<ivit_linear_plan> plans;   // per block: qkv, proj, fc1, fc2 (frozen QuantLinear plans, ivit_linear_plan_create)
     std::vector<ivit_mlp_plan> mlp_plans;  // per block: fused Mlp plan (D = 384), or null -> fc1 / ShiftGELU / fc2 launches
     int max_slices;
@@ -27,6 +29,10 @@ struct ivit_graph_s {
     hipGraph_t graph;
     hipGraphExec_t exec;
 };
+
+#ifndef IVIT_OPT_ATTN_ROWTAB
+#define IVIT_OPT_ATTN_ROWTAB 1         // A/B: Shiftmax by row tables (one gather per score) where a layer's table lines fit
+#endif
 
 namespace {
 
@@ -90,7 +96,10 @@ int run_slice(const ivit_vit_s *m, ivit_handle h, const int8_t *images, int B, i
         RUN(ivit_layernorm_requant(h, x, M, D, D, b.s_ln1, b.n1_bias_int, b.n1_sc, b.n1_dy, a8));
         RUN(ivit_linear_i8_qkv_planned(h, m->plans[4 * i], a8, q, k, vt, B, T, H, dh, ld));
         if (m->fused_attention) {
-            if (b.exp_aq)
+            if (m->has_rowtab[i])      // one gather per score (round 6)
+                RUN(ivit_attention_fused_rowlut(h, q, k, vt, b.dy_qk, b.s_softmax, m->rowtab + (size_t)i * 256 * 64, b.exp_dmin, b.dy_pv,
+                                                ctx8, B, H, T, dh, ld));
+            else if (b.exp_aq)
                 RUN(ivit_attention_fused_lut(h, q, k, vt, b.dy_qk, b.s_softmax, b.exp_aq, b.exp_t, b.exp_cls, b.exp_nc,
                                              b.exp_tcount, b.exp_dmin, b.dy_pv, ctx8, B, H, T, dh, ld));
             else
@@ -150,9 +159,12 @@ int ivit_vit_create(ivit_handle h, const ivit_vit_config *cfg, const ivit_vit_pa
     m->Kp = cfg->in_chans * cfg->patch_size * cfg->patch_size;
     m->fused_attention = (cfg->embed_dim / cfg->num_heads == 64) && m->T <= 640;
     m->gelu_tab = nullptr;
+    m->rowtab = nullptr;
+    m->has_rowtab.assign(cfg->depth, 0);
     m->max_slices = max_slices;
     m->fork = nullptr;
     hipError_t e = hipMalloc((void **)&m->gelu_tab, (size_t)cfg->depth * 65536);
+    if (e == hipSuccess && m->fused_attention && IVIT_OPT_ATTN_ROWTAB) e = hipMalloc((void **)&m->rowtab, (size_t)cfg->depth * 256 * 64 * sizeof(float));
     if (e != hipSuccess) {
         snprintf(h->err, sizeof(h->err), "ivit_vit_create: hipMalloc: %s", hipGetErrorString(e));
         delete m;
@@ -163,6 +175,11 @@ int ivit_vit_create(ivit_handle h, const ivit_vit_config *cfg, const ivit_vit_pa
         if (rc != IVIT_OK) { ivit_vit_destroy(m); return rc; }
         // frozen QuantLinear plans: per-channel multipliers and the exactness bounds of the pipelined GEMMs
         const ivit_vit_block &b = m->blocks[i];
+        if (m->rowtab && b.exp_aq && 1 - b.exp_dmin <= 64 && fabs(b.dy_qk.m * b.dy_qk.r) < 512.0 && fabs(b.dy_pv.m * b.dy_pv.r) < 512.0) {
+            rc = ivit_shiftmax_rowtable(h, b.exp_aq, b.exp_t, b.exp_cls, b.exp_nc, b.exp_tcount, b.exp_dmin, m->rowtab + (size_t)i * 256 * 64);
+            if (rc != IVIT_OK) { ivit_vit_destroy(m); return rc; }
+            m->has_rowtab[i] = 1;
+        }
         const int D = cfg->embed_dim, Hd = cfg->hidden_dim;
         const struct { const int8_t *w; const int32_t *bias; const ivit_dyadic *dy; int N, K; } lin[4] = {
             {b.qkv_w, b.qkv_b, b.qkv_dy, 3 * D, D}, {b.proj_w, b.proj_b, b.proj_dy, D, D},
@@ -208,6 +225,7 @@ int ivit_vit_destroy(ivit_vit m) {
     for (auto st : m->streams) (void)hipStreamDestroy(st);
     if (m->fork) (void)hipEventDestroy(m->fork);
     if (m->gelu_tab) (void)hipFree(m->gelu_tab);
+    if (m->rowtab) (void)hipFree(m->rowtab);
     for (auto mp : m->mlp_plans) if (mp) (void)ivit_mlp_plan_destroy(mp);
     for (auto pl : m->plans) (void)ivit_linear_plan_destroy(pl);
     delete m;

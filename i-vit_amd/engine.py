@@ -121,6 +121,23 @@ class ViTEngine:
             self.h.call("ivit_shiftgelu_build_table", self.f32[p + "mlp.s_gelu"], _dy(self.host[p + "mlp.dy_gelu"]),
                         _P(self.gelu_tab[i].data_ptr()))
 
+        # Shiftmax row tables (one gather per score, ivit_attention_fused_rowlut) for the layers whose table lines fit 64 entries
+        # and whose requant multipliers are in the kernel's fast range — the per-operator path makes the runner's choice
+        self.use_row_tables = True
+        self.rowtab = {}
+        if self.fused_attention:
+            for i in range(cfg.depth):
+                p = f"blocks.{i}."
+                if p + "attn.exp_meta" not in self.host:
+                    continue
+                meta = self.host[p + "attn.exp_meta"]
+                dqk, dpv = self.host[p + "attn.dy_qk"], self.host[p + "attn.dy_pv"]
+                if 1 - int(meta[2]) <= 64 and abs(dqk[0, 0] * dqk[0, 1]) < 512.0 and abs(dpv[0, 0] * dpv[0, 1]) < 512.0:
+                    t = torch.empty(256, 64, dtype=torch.float32, device=self.device)
+                    self.h.call("ivit_shiftmax_rowtable", self.ptr(p + "attn.exp_aq"), self.ptr(p + "attn.exp_t"), self.ptr(p + "attn.exp_cls"),
+                                int(meta[0]), int(meta[1]), int(meta[2]), _P(t.data_ptr()))
+                    self.rowtab[i] = t
+
         # frozen-QuantLinear plans of the per-operator path (forward_ops / plan()): built on first use by build_op_plans()
         # — plan creation allocates and synchronises, so callers that time or capture forward_ops call it beforehand; the
         # native runner (forward) holds its own plans, and an engine that only runs forward() no longer keeps a second
@@ -313,7 +330,11 @@ class ViTEngine:
                 call("ivit_linear_i8_qkv", P(ws["a8"]), self.ptr(p + "attn.qkv.w"), self.ptr(p + "attn.qkv.b"),
                      self.ptr(p + "attn.qkv.dy"), P(ws["q"]), P(ws["k"]), P(ws["vt"]), B, T, H, dh, ld)
             if self.fused_attention:
-                if p + "attn.exp_meta" in hc and self.use_exp_tables:
+                if i in self.rowtab and self.use_exp_tables and self.use_row_tables:
+                    call("ivit_attention_fused_rowlut", P(ws["q"]), P(ws["k"]), P(ws["vt"]), _dy(hc[p + "attn.dy_qk"]),
+                         f32[p + "attn.s_softmax"], P(self.rowtab[i]), int(hc[p + "attn.exp_meta"][2]),
+                         _dy(hc[p + "attn.dy_pv"]), P(ws["ctx8"]), B, H, T, dh, ld)
+                elif p + "attn.exp_meta" in hc and self.use_exp_tables:
                     meta = hc[p + "attn.exp_meta"]
                     call("ivit_attention_fused_lut", P(ws["q"]), P(ws["k"]), P(ws["vt"]), _dy(hc[p + "attn.dy_qk"]),
                          f32[p + "attn.s_softmax"], self.ptr(p + "attn.exp_aq"), self.ptr(p + "attn.exp_t"),

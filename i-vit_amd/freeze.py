@@ -205,3 +205,24 @@ def shiftmax_tables(s, max_bytes=24 * 1024):
         if not np.array_equal(direct, tab):
             raise AssertionError(f"shiftmax table mismatch at vmax index {qi} for scale {float(s)!r}")
     return dict(cls=cls, aq=np.ascontiguousarray(aq), t=T.reshape(-1), R=R, dmin=dmin, NC=NC, NE=NE)
+
+
+def shiftmax_rowtable(tabs):
+    """Row form of the Shiftmax tables (csrc/ivit_attention.h, LUT = 2): rowtab[vmax + 128][dd] = exp_int of the score
+    v = vmax + dmin + dd in a row whose maximum is vmax, dd = max(v - vmax, dmin) - dmin; float32 [256, 64].  None when a line
+    does not fit 64 entries (R = 1 - dmin > 64).  The device builds the same table itself (ivit_shiftmax_rowtable); this copy
+    serves the tests."""
+    if tabs is None or tabs["R"] > 64:
+        return None
+    R, dmin = int(tabs["R"]), int(tabs["dmin"])
+    aq, t, cls = tabs["aq"].astype(np.int64), tabs["t"], tabs["cls"].astype(np.int64)
+    out = np.zeros((256, 64), np.float32)
+    for q in range(256):
+        for dd in range(R):
+            vi = q + dmin + dd
+            if vi < 0:
+                if dd:
+                    continue                      # a score below -128: never indexed
+                vi = 0                            # entry 0 is the floor constant whatever the class
+            out[q, dd] = t[aq[cls[q], vi] + dd]
+    return out

@@ -48,11 +48,12 @@ enum {
     IVIT_ERR_NO_DEVICE = 4
 };
 
-/* 100 * major + minor.  101 (round 5): ivit_mlp_plan_select; ivit_swin_block / ivit_vit_block carry the optional Shiftmax-table
+/* 100 * major + minor.  102 (round 6): ivit_shiftmax_rowtable, ivit_attention_fused_rowlut (additions only).
+ * 101 (round 5): ivit_mlp_plan_select; ivit_swin_block / ivit_vit_block carry the optional Shiftmax-table
  * fields exp_* at their END (added in 100 without a bump: a caller compiled against an older layout must be rebuilt).
  * Parameter structs are read field by field: ZERO-INITIALISE them (memset / = {0}) before filling — exp_aq == NULL (and
  * exp_nc == exp_tcount == exp_dmin == 0) selects the arithmetic Shiftmax, anything else is taken as device pointers.        */
-#define IVIT_VERSION 101
+#define IVIT_VERSION 102
 int ivit_version(void);
 const char *ivit_status_string(int status);
 
@@ -177,6 +178,21 @@ int ivit_attention_fused_lut(ivit_handle h, const int8_t *q, const int8_t *k, co
                              ivit_dyadic dy_qk, float s_softmax, const uint16_t *exp_aq, const float *exp_t,
                              const uint8_t *exp_cls, int nclass, int t_count, int dmin, ivit_dyadic dy_pv,
                              int8_t *ctx8, int B, int H, int T, int dh, int ldv);
+
+/* Row form of the same tables (round 6).  In a score row with maximum vmax only the scores v in (vmax + dmin, vmax] have an
+ * exp_int above the floor constant (IntSoftmax.int_exp_shift, quant_modules.py:469-481), so exp_int as a function of
+ * dd = max(v - vmax, dmin) - dmin is ONE line of R = 1 - dmin entries per value of vmax:
+ *     rowtab[vmax + 128][dd] = exp_t[exp_aq[exp_cls[vmax]][vmax + dmin + dd] + dd],   float [256][64] (device, 16-byte aligned).
+ * ivit_shiftmax_rowtable builds it on the device from the tables of ivit_attention_fused_lut (IVIT_ERR_UNSUPPORTED when a
+ * line does not fit: 1 - dmin > 64; the two-level form then stays); ivit_attention_fused_rowlut is ivit_attention_fused with
+ * ONE table gather per score: a wavefront fetches the 16 lines of its query tile once the row maxima are known.  Needs
+ * |m 2^-e| < 2^9 for both requant multipliers (IVIT_ERR_UNSUPPORTED otherwise).  Same integers as ivit_attention_fused
+ * (vit_quant.py:70-83).                                                                                              */
+int ivit_shiftmax_rowtable(ivit_handle h, const uint16_t *exp_aq, const float *exp_t, const uint8_t *exp_cls,
+                           int nclass, int t_count, int dmin, float *rowtab);
+int ivit_attention_fused_rowlut(ivit_handle h, const int8_t *q, const int8_t *k, const int8_t *vt,
+                                ivit_dyadic dy_qk, float s_softmax, const float *rowtab, int dmin, ivit_dyadic dy_pv,
+                                int8_t *ctx8, int B, int H, int T, int dh, int ldv);
 
 /* ---- a3  QuantAct.forward with a previous scale -> fixedpoint_mul.forward
  * (quant_modules.py:197-206, quant_utils.py:192-253).  z int32 or float (integer-valued;

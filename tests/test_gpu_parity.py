@@ -975,6 +975,20 @@ def test_attention_shiftmax_tables_equal_arithmetic(H, scale):
                P(dev(tabs["cls"])), int(tabs["NC"]), int(tabs["t"].size), int(tabs["dmin"]), dyv(dpv), P(o2), B, Hh, T, dh, ld)
         assert np.array_equal(o1.cpu().numpy(), o2.cpu().numpy()), (scale, T)
         assert len(np.unique(o1.cpu().numpy())) > 20
+        # round 6: the ROW form of the tables (one gather per score).  The device-built table equals the host restatement
+        # (freeze.shiftmax_rowtable) entry for entry; a scale whose lines need more than 64 entries is refused, not truncated
+        rt = torch.full((256, 64), -1.0, dtype=torch.float32, device="cuda")
+        rt_args = (P(dev(tabs["aq"])), P(dev(tabs["t"])), P(dev(tabs["cls"])), int(tabs["NC"]), int(tabs["t"].size), int(tabs["dmin"]), P(rt))
+        if tabs["R"] <= 64:
+            H.call("ivit_shiftmax_rowtable", *rt_args)
+            assert np.array_equal(rt.cpu().numpy(), iv.freeze.shiftmax_rowtable(tabs))
+            o3 = torch.full_like(o1, 9)
+            H.call("ivit_attention_fused_rowlut", P(q), P(k), P(vt), dyv(dqk), float(scale), P(rt), int(tabs["dmin"]), dyv(dpv), P(o3), B, Hh, T, dh, ld)
+            assert np.array_equal(o1.cpu().numpy(), o3.cpu().numpy()), (scale, T, "row tables")
+        else:
+            assert iv.freeze.shiftmax_rowtable(tabs) is None
+            with pytest.raises(_lib.IvitError, match="64 entries"):
+                H.call("ivit_shiftmax_rowtable", *rt_args)
     # the tables are copied in 16-byte pieces: a misaligned exp_t is refused, not mis-read
     shifted = dev(np.concatenate([np.zeros(1, np.float32), tabs["t"]]))
     with pytest.raises(_lib.IvitError, match="16-byte aligned"):
@@ -1511,8 +1525,8 @@ def test_fused_attention_core_vs_oracle(H, T, kind):
     q.k^T -> qact_attn1 -> Shiftmax(16) -> attn.v -> qact2 (vit_quant.py:70-83) at the token counts of the 224- and
     384-pixel models and at the edges of the three kernel sizes (1, 64 | 65, 256 | 257, 640 keys: run-time token count, ragged
     last query tile, every wavefront-to-tile assignment), with score rows spread over the int8 range, peaky rows (one dominant
-    key: the factor flips) and saturated rows (many scores clamped at +-127/-128); both the arithmetic and the table-driven
-    Shiftmax variants."""
+    key: the factor flips) and saturated rows (many scores clamped at +-127/-128); the arithmetic Shiftmax and both table-driven
+    forms (two-level tables, row tables)."""
     from oracle import oracle as orc
     rng = np.random.default_rng(T + len(kind))
     B, Hh, dh = 2, 2, 64
@@ -1554,6 +1568,11 @@ def test_fused_attention_core_vs_oracle(H, T, kind):
     H.call("ivit_attention_fused_lut", P(qd), P(kd), P(vd), dyv(dqk_h), float(scale), P(dev(tabs["aq"])), P(dev(tabs["t"])),
            P(dev(tabs["cls"])), int(tabs["NC"]), int(tabs["t"].size), int(tabs["dmin"]), dyv(dpv_h), P(o2), B, Hh, T, dh, ld)
     assert np.array_equal(o2.cpu().numpy().astype(np.int32), ref), (T, kind, "tables")
+    rt = torch.empty(256, 64, dtype=torch.float32, device="cuda")
+    H.call("ivit_shiftmax_rowtable", P(dev(tabs["aq"])), P(dev(tabs["t"])), P(dev(tabs["cls"])), int(tabs["NC"]), int(tabs["t"].size), int(tabs["dmin"]), P(rt))
+    o3 = torch.full_like(o1, 9)
+    H.call("ivit_attention_fused_rowlut", P(qd), P(kd), P(vd), dyv(dqk_h), float(scale), P(rt), int(tabs["dmin"]), dyv(dpv_h), P(o3), B, Hh, T, dh, ld)
+    assert np.array_equal(o3.cpu().numpy().astype(np.int32), ref), (T, kind, "row tables")
     assert len(np.unique(ref)) > 10
 
 
