@@ -82,7 +82,10 @@ struct AttCfg {
 #ifndef ATT_MINW           // waves per SIMD the kernel is compiled for (probe; 1 = whatever the workgroup size implies)
 #define ATT_MINW 1
 #endif
-template <int NB, bool FAST, int TT = 0, int LUT = 0>
+// VROW (round 6, with LUT = 2): v arrives ROW-major [B*H, T, 64] like q and k (p.ldv == 0) and is transposed on its way into the
+// LDS — four keys x 16 channels per thread, byte-transposed in registers with v_perm — instead of v^T [B*H, 64, ldv] written by the
+// qkv GEMM with sixteen byte stores per token (which cost that GEMM ~20 % of its time).
+template <int NB, bool FAST, int TT = 0, int LUT = 0, bool VROW = false>
 __global__ __launch_bounds__(ATT_WAVES * 64, ATT_MINW) void attn_fused_kernel(AttnArgs p) {
     using C = AttCfg<NB>;
     extern __shared__ __attribute__((aligned(16))) char dsmem[];
@@ -105,13 +108,13 @@ __global__ __launch_bounds__(ATT_WAVES * 64, ATT_MINW) void attn_fused_kernel(At
     if (LUT && (unsigned)(size_t)((__attribute__((address_space(3))) char *)dsmem) != 0u) __builtin_trap();
     const int8_t *qg = p.q + (long long)bh * T * 64;
     const int8_t *kg = p.k + (long long)bh * T * 64;
-    const int8_t *vg = p.vt + (long long)bh * 64 * p.ldv;
+    const int8_t *vg = p.vt + (VROW ? (long long)bh * T * 64 : (long long)bh * 64 * p.ldv);
 
     // ---- stage K (rows >= T zero) and V^T (keys >= T zero, permuted) into LDS, and the tables.
     // Every global load of the prologue is issued before the first one is waited for (round 4: written as load-store
     // loops it was ~20 serial memory latencies per workgroup, 9 us of the launch when timed alone)
     constexpr int NTH = ATT_WAVES * 64;
-    constexpr int KI = (C::TK * 4 + NTH - 1) / NTH, VI = (64 * C::NT + NTH - 1) / NTH;
+    constexpr int KI = (C::TK * 4 + NTH - 1) / NTH, VI = VROW ? 4 * ((C::NT * 16 + NTH - 1) / NTH) : (64 * C::NT + NTH - 1) / NTH;
     v4i kreg[KI], vreg[VI];
 
 #pragma unroll
@@ -120,11 +123,24 @@ __global__ __launch_bounds__(ATT_WAVES * 64, ATT_MINW) void attn_fused_kernel(At
         kreg[i] = v4i{0, 0, 0, 0};
         if (c < C::TK * 4 && row < T) kreg[i] = *reinterpret_cast<const v4i *>(kg + row * 64 + g * 16);
     }
+    if constexpr (VROW) {
+        // item c = (key quad c >> 2, channel group c & 3): rows 4 tq .. 4 tq + 3, bytes [16 dg, 16 dg + 16) — four lanes cover a row
+#pragma unroll
+        for (int i = 0; i < VI / 4; ++i) {
+            const int c = tid + i * NTH, tq = c >> 2, dg = c & 3;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                vreg[4 * i + r] = v4i{0, 0, 0, 0};
+                if (c < C::NT * 16 && 4 * tq + r < T) vreg[4 * i + r] = *reinterpret_cast<const v4i *>(vg + (4 * tq + r) * 64 + dg * 16);
+            }
+        }
+    } else {
 #pragma unroll
     for (int i = 0; i < VI; ++i) {
         const int c = tid + i * NTH, d = c / C::NT, t0 = (c - d * C::NT) * 16;
         vreg[i] = v4i{0, 0, 0, 0};
         if (c < 64 * C::NT && t0 < T) vreg[i] = *reinterpret_cast<const v4i *>(vg + (long long)d * p.ldv + t0);
+    }
     }
     if (LUT == 1 && !(ATT_PROBE & 32)) {
         // table offsets are staged as BYTE offsets into sT (x4: t_count <= 16384 keeps them in 16 bits): a score's
@@ -153,6 +169,28 @@ __global__ __launch_bounds__(ATT_WAVES * 64, ATT_MINW) void attn_fused_kernel(At
         const int c = tid + i * NTH, row = c >> 2, g = c & 3;
         if (c < C::TK * 4) *reinterpret_cast<v4i *>(sK + row * 64 + att_kswz(row, g) * 16) = kreg[i];
     }
+    if constexpr (VROW) {
+        // 4 x 4 byte transposes: dword w of the four rows -> for each channel 16 dg + 4 w + b one dword of four consecutive keys,
+        // stored where the v^T path puts keys 4 tq .. 4 tq + 3 of that channel (block kb, position 16 g + 4 jj inside it)
+#pragma unroll
+        for (int i = 0; i < VI / 4; ++i) {
+            const int c = tid + i * NTH, tq = c >> 2, dg = c & 3;
+            if (c < C::NT * 16) {
+                const int k = (4 * tq) & 63, pos = ((4 * tq) >> 6) * 64 + ((k >> 2) & 3) * 16 + (k >> 4) * 4;
+                char *dst = sV + (dg * 16) * C::VS + pos;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const unsigned r0 = (unsigned)vreg[4 * i][w], r1 = (unsigned)vreg[4 * i + 1][w], r2 = (unsigned)vreg[4 * i + 2][w], r3 = (unsigned)vreg[4 * i + 3][w];
+                    const unsigned a01l = __builtin_amdgcn_perm(r1, r0, 0x05010400u), a01h = __builtin_amdgcn_perm(r1, r0, 0x07030602u);
+                    const unsigned a23l = __builtin_amdgcn_perm(r3, r2, 0x05010400u), a23h = __builtin_amdgcn_perm(r3, r2, 0x07030602u);
+                    *reinterpret_cast<unsigned *>(dst + (4 * w + 0) * C::VS) = __builtin_amdgcn_perm(a23l, a01l, 0x05040100u);
+                    *reinterpret_cast<unsigned *>(dst + (4 * w + 1) * C::VS) = __builtin_amdgcn_perm(a23l, a01l, 0x07060302u);
+                    *reinterpret_cast<unsigned *>(dst + (4 * w + 2) * C::VS) = __builtin_amdgcn_perm(a23h, a01h, 0x05040100u);
+                    *reinterpret_cast<unsigned *>(dst + (4 * w + 3) * C::VS) = __builtin_amdgcn_perm(a23h, a01h, 0x07060302u);
+                }
+            }
+        }
+    } else {
 #pragma unroll
     for (int i = 0; i < VI; ++i) {
         const int c = tid + i * NTH, d = c / C::NT, ci = c - d * C::NT, t0 = ci * 16;   // ci: 16-key chunk index
@@ -173,17 +211,18 @@ __global__ __launch_bounds__(ATT_WAVES * 64, ATT_MINW) void attn_fused_kernel(At
             for (int g = 0; g < 4; ++g) *reinterpret_cast<int *>(dst + g * 16) = v[g];
         }
     }
+    }
     if (tid < 256) sXq[tid] = requotient_c((float)(tid - 128), rcp_prepare(p.s_softmax));
     if (tid < 64) sCol[tid] = 0;
     __syncthreads();
     {   // column sums of V (per d) over all keys: every wave takes 1 / ATT_WAVES of the keys of all 64 columns and adds its
         // partial sum with one LDS atomic (round 6: one wave walking all TK / 4 words was a ~2 us serial section per workgroup)
-        static_assert((C::TK / 4) % ATT_WAVES == 0, "whole words per wave");
-        constexpr int WPP = C::TK / 4 / ATT_WAVES;
+        constexpr int WPP = (C::TK / 4 + ATT_WAVES - 1) / ATT_WAVES;
         int s = 0;
-        const int *row = reinterpret_cast<const int *>(sV + lane * C::VS) + wave * WPP;
+        const int *row = reinterpret_cast<const int *>(sV + lane * C::VS);
 #pragma unroll
-        for (int w = 0; w < WPP; ++w) s = __builtin_amdgcn_sdot4(row[w], 0x01010101, s, false);
+        for (int w = 0; w < WPP; ++w)
+            if ((C::TK / 4) % ATT_WAVES == 0 || wave * WPP + w < C::TK / 4) s = __builtin_amdgcn_sdot4(row[wave * WPP + w], 0x01010101, s, false);
         atomicAdd(&sCol[lane], s);
     }
     __syncthreads();

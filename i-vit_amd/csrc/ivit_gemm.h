@@ -316,8 +316,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
                 int head = within / p.dh, d0 = within - head * p.dh;
                 int b = grow / p.T, t = grow - b * p.T;
                 long long bh = (long long)b * p.H + head;
-                if (which < 2) {
-                    int8_t *dst = (which == 0 ? p.q : p.k) + (bh * p.T + t) * p.dh + d0;
+                if (which < 2 || p.ldv == 0) {
+                    int8_t *dst = (which == 0 ? p.q : (which == 1 ? p.k : p.vt)) + (bh * p.T + t) * p.dh + d0;
                     *reinterpret_cast<v4i *>(dst) = v;
                 } else {
                     const int8_t *s = reinterpret_cast<const int8_t *>(&v);

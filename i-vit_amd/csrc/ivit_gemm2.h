@@ -310,8 +310,8 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 4 : (G2_NSTAGE128 == 2 ? 4 : 3)
                 if (t < 0) { --b; t += p.T; }
                 if (t >= p.T) { ++b; t -= p.T; }
                 long long bh = (long long)b * p.H + head;
-                if (which < 2) {
-                    int8_t *dst = (which == 0 ? p.q : p.k) + (bh * p.T + t) * p.dh + d0;
+                if (which < 2 || p.ldv == 0) {
+                    int8_t *dst = (which == 0 ? p.q : (which == 1 ? p.k : p.vt)) + (bh * p.T + t) * p.dh + d0;
                     *reinterpret_cast<v4i *>(dst) = v;
                 } else {
                     int8_t *dst = p.vt + (bh * p.dh + d0) * p.ldv + t;

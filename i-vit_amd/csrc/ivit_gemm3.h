@@ -279,8 +279,8 @@ __global__ __launch_bounds__(G3Cfg<ASTAT>::NT, 2) void gemm_ps_kernel(GemmArgs p
                         const int head = g3_div(within, p.dh, rcpdh), d0 = within - head * p.dh;
                         const int b = g3_div(grow, p.T, rcpT), t = grow - b * p.T;
                         const long long bh = (long long)b * p.H + head;
-                        if (which < 2) {
-                            int8_t *dst = (which == 0 ? p.q : p.k) + (bh * p.T + t) * p.dh + d0;
+                        if (which < 2 || p.ldv == 0) {          // ldv == 0: v row-major like q and k (round 6)
+                            int8_t *dst = (which == 0 ? p.q : (which == 1 ? p.k : p.vt)) + (bh * p.T + t) * p.dh + d0;
                             *reinterpret_cast<v4i *>(dst) = v;
                         } else {
                             int8_t *dst = p.vt + (bh * p.dh + d0) * p.ldv + t;
@@ -830,11 +830,11 @@ __global__ __launch_bounds__(512, 2) void gemm_as_kernel(GemmArgs p) {
                 const int gr = ok ? grow : 0;
                 const int b = g3_div(gr, p.T, rcpT), t = gr - b * p.T;
                 const unsigned bh = (unsigned)(b * p.H + head);
-                if (which < 2) {
+                if (which < 2 || p.ldv == 0) {                  // ldv == 0: v row-major like q and k — one 16-byte store per lane
                     const unsigned off = ok ? (bh * (unsigned)p.T + (unsigned)t) * (unsigned)p.dh + (unsigned)d0 : GA_OOB;
-                    __builtin_amdgcn_raw_buffer_store_b128((v4u)v, ga_rsrc(which == 0 ? p.q : p.k), off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128((v4u)v, ga_rsrc(which == 0 ? p.q : (which == 1 ? p.k : p.vt)), off, 0, 0);
                     issued += 1;
-                } else {
+                } else {                                        // v^T: sixteen byte stores per lane (the layout ivit_attn_pv_requant reads)
                     const unsigned off = ok ? (bh * (unsigned)p.dh + (unsigned)d0) * (unsigned)p.ldv + (unsigned)t : GA_OOB;
                     const __amdgpu_buffer_rsrc_t rs = ga_rsrc(p.vt);
 #pragma unroll

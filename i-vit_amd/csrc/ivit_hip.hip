@@ -293,7 +293,7 @@ int ivit_linear_i8_qkv(ivit_handle h, const int8_t *x, const int8_t *w, const in
     CHECK_H(h);
     REQUIRE(h, x && w && dy_ch && q && k && vt && B > 0 && T > 0 && H > 0 && dh > 0, "bad arguments");
     REQUIRE(h, (dh % 16) == 0, "head dim must be a multiple of 16");
-    REQUIRE(h, ldv >= T, "ldv < T");
+    REQUIRE(h, ldv == 0 || ldv >= T, "ldv < T (0 = v row-major [B*H, T, dh])");
     const int D = H * dh;
     GemmArgs a = linear_args(x, w, bias, B * T, 3 * D, D);
     a.dy_ch = dy_ch; a.q = q; a.k = k; a.vt = vt;
@@ -623,7 +623,7 @@ int ivit_linear_i8_qkv_planned(ivit_handle h, ivit_linear_plan pl, const int8_t 
     CHECK_H(h);
     REQUIRE(h, pl && x && q && k && vt && B > 0 && T > 0 && H > 0 && dh > 0, "bad arguments");
     REQUIRE(h, (dh % 16) == 0, "head dim must be a multiple of 16");
-    REQUIRE(h, ldv >= T, "ldv < T");
+    REQUIRE(h, ldv == 0 || ldv >= T, "ldv < T (0 = v row-major [B*H, T, dh])");
     const int D = H * dh;
     REQUIRE(h, pl->N == 3 * D && pl->K == D, "plan shape is not [3*H*dh, H*dh]");
     GemmArgs a = linear_args(x, pl->w, pl->bias, B * T, 3 * D, D);
@@ -749,16 +749,16 @@ int ivit_mlp_fused_planned(ivit_handle h, ivit_mlp_plan p, const int8_t *x, cons
 
 }  // extern "C"
 
-template <int NB, bool FAST, int TT = 0, int LUT = 0>
+template <int NB, bool FAST, int TT = 0, int LUT = 0, bool VROW = false>
 static int launch_attn2(ivit_handle h, const AttnArgs &a, int BH) {
     const size_t lds = AttCfg<NB>::SMEM + (LUT == 2 ? (size_t)ATT_ROWLINE_BYTES
                                                    : (LUT == 1 ? (size_t)((a.t_count + 3) & ~3) * 4 + (size_t)a.nc * 512 + 256 : 0));
     if (lds > 65536) {
-        hipError_t e = hipFuncSetAttribute((const void *)attn_fused_kernel<NB, FAST, TT, LUT>,
+        hipError_t e = hipFuncSetAttribute((const void *)attn_fused_kernel<NB, FAST, TT, LUT, VROW>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { snprintf(h->err, sizeof(h->err), "attn attr: %s", hipGetErrorString(e)); return IVIT_ERR_HIP; }
     }
-    attn_fused_kernel<NB, FAST, TT, LUT><<<BH, ATT_WAVES * 64, lds, h->stream>>>(a);
+    attn_fused_kernel<NB, FAST, TT, LUT, VROW><<<BH, ATT_WAVES * 64, lds, h->stream>>>(a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(h->err, sizeof(h->err), "attn launch: %s", hipGetErrorString(e)); return IVIT_ERR_HIP; }
     return IVIT_OK;
@@ -771,6 +771,11 @@ static int launch_attn(ivit_handle h, const AttnArgs &a, int BH) {
     constexpr bool dyn_t = (IVIT_OPT_ATTN_GENERIC & 1) != 0, no_lut = (IVIT_OPT_ATTN_GENERIC & 2) != 0;
     const bool lut = a.aq && a.et && a.cls && !no_lut;
     if (a.rowtab) {     // row-line tables (ivit_attention_fused_rowlut): the multipliers were checked by the caller
+        if (a.ldv == 0) {   // v row-major
+            if (NB == 4 && a.T == 197 && !dyn_t) return launch_attn2<NB, true, 197, 2, true>(h, a, BH);
+            if (NB == 10 && a.T == 577 && !dyn_t) return launch_attn2<NB, true, 577, 2, true>(h, a, BH);
+            return launch_attn2<NB, true, 0, 2, true>(h, a, BH);
+        }
         if (NB == 4 && a.T == 197 && !dyn_t) return launch_attn2<NB, true, 197, 2>(h, a, BH);
         if (NB == 10 && a.T == 577 && !dyn_t) return launch_attn2<NB, true, 577, 2>(h, a, BH);
         return launch_attn2<NB, true, 0, 2>(h, a, BH);
@@ -789,7 +794,7 @@ static int attention_fused_impl(ivit_handle h, const int8_t *q, const int8_t *k,
                                 const float *rowtab = nullptr) {
     CHECK_H(h);
     REQUIRE(h, q && k && vt && ctx8 && B > 0 && H > 0 && T > 0 && s_softmax > 0.f, "bad arguments");
-    REQUIRE(h, (ldv % 16) == 0 && ldv >= T, "ldv must be a multiple of 16 and >= T");
+    REQUIRE(h, ((ldv % 16) == 0 && ldv >= T) || (ldv == 0 && rowtab), "ldv must be a multiple of 16 and >= T (0 = v row-major: ivit_attention_fused_rowlut only)");
     if (dh != 64 || T > 640) {
         snprintf(h->err, sizeof(h->err), "ivit_attention_fused: built for dh == 64, T <= 640");
         return IVIT_ERR_UNSUPPORTED;

@@ -151,9 +151,13 @@ struct LnGroup {
     }
 
     // cb0 = 8 k + EPC h: this lane's first channel of every 32-element step; op = out + row * CC + cb0
+    // DMA_SYNC: the constants arrive by LDS-DMA (planned kernel): wait for them — this wave's own transfers by vmcnt, the other
+    // waves' by the barrier — in front of the output pass, the first reader
+    template <typename DMA_SYNC = std::false_type>
     static __device__ __forceinline__ void run(float (&xv)[NSTEP][EPC], int j, int k, int cb0, bool fastrq, bool live,
                                                const double *cC, const float *cB, const float *cSc, const float *cY,
-                                               const float *bias_int, const float *sc, const ivit_dyadic *dy, int8_t *op) {
+                                               const float *bias_int, const float *sc, const ivit_dyadic *dy, int8_t *op,
+                                               DMA_SYNC = DMA_SYNC{}) {
         // ---- first sum
         float a0[EPC], a1[EPC];
 #pragma unroll
@@ -190,6 +194,10 @@ struct LnGroup {
         }
         const float F = floorf((1.0f / kk) * 2147483648.0f);
         const float Fh = F * 0.5f;       // fl(fl(y * F) * 0.5) == fl(y * (F * 0.5)): the power of two commutes with the rounding
+        if constexpr (DMA_SYNC::value) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
 
         // ---- pass 3: normalise, requotient by the channel scale, 8-bit requant, store
         auto pass3 = [&](auto fast) {

@@ -30,6 +30,9 @@ struct ivit_graph_s {
     hipGraphExec_t exec;
 };
 
+#ifndef IVIT_OPT_V_ROWMAJOR
+#define IVIT_OPT_V_ROWMAJOR 1          // A/B: v row-major between the qkv GEMM and the row-table attention
+#endif
 #ifndef IVIT_OPT_ATTN_ROWTAB
 #define IVIT_OPT_ATTN_ROWTAB 1         // A/B: Shiftmax by row tables (one gather per score) where a layer's table lines fit
 #endif
@@ -94,11 +97,14 @@ int run_slice(const ivit_vit_s *m, ivit_handle h, const int8_t *images, int B, i
     for (int i = 0; i < c.depth; ++i) {
         const ivit_vit_block &b = m->blocks[i];
         RUN(ivit_layernorm_requant(h, x, M, D, D, b.s_ln1, b.n1_bias_int, b.n1_sc, b.n1_dy, a8));
-        RUN(ivit_linear_i8_qkv_planned(h, m->plans[4 * i], a8, q, k, vt, B, T, H, dh, ld));
+        // a layer on the row-table attention takes v ROW-major (ldv = 0: the qkv GEMM stores 16 bytes per lane instead of 16 byte
+        // stores, the attention kernel transposes on its way into the LDS); the other attention forms read v^T
+        const int ldv = (m->fused_attention && m->has_rowtab[i] && IVIT_OPT_V_ROWMAJOR) ? 0 : ld;
+        RUN(ivit_linear_i8_qkv_planned(h, m->plans[4 * i], a8, q, k, vt, B, T, H, dh, ldv));
         if (m->fused_attention) {
             if (m->has_rowtab[i])      // one gather per score (round 6)
                 RUN(ivit_attention_fused_rowlut(h, q, k, vt, b.dy_qk, b.s_softmax, m->rowtab + (size_t)i * 256 * 64, b.exp_dmin, b.dy_pv,
-                                                ctx8, B, H, T, dh, ld));
+                                                ctx8, B, H, T, dh, ldv));
             else if (b.exp_aq)
                 RUN(ivit_attention_fused_lut(h, q, k, vt, b.dy_qk, b.s_softmax, b.exp_aq, b.exp_t, b.exp_cls, b.exp_nc,
                                              b.exp_tcount, b.exp_dmin, b.dy_pv, ctx8, B, H, T, dh, ld));

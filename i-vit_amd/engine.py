@@ -124,6 +124,7 @@ class ViTEngine:
         # Shiftmax row tables (one gather per score, ivit_attention_fused_rowlut) for the layers whose table lines fit 64 entries
         # and whose requant multipliers are in the kernel's fast range — the per-operator path makes the runner's choice
         self.use_row_tables = True
+        self.v_row_major = True         # forward_ops: v row-major into the row-table attention (False: v^T as before)
         self.rowtab = {}
         if self.fused_attention:
             for i in range(cfg.depth):
@@ -323,17 +324,20 @@ class ViTEngine:
             p = f"blocks.{i}."
             call("ivit_layernorm_requant", P(x), M, D, D, f32[p + "ln1.s"], self.ptr(p + "norm1.bias_int"),
                  self.ptr(p + "norm1.sc"), self.ptr(p + "norm1.dy"), P(ws["a8"]))
+            # the runner's choice (csrc/ivit_model.h): v ROW-major (ldv = 0) between the planned qkv GEMM and the row-table attention
+            row_attn = self.fused_attention and i in self.rowtab and self.use_exp_tables and self.use_row_tables
+            ldv = 0 if (row_attn and self.use_plans and self.v_row_major) else ld
             if self.use_plans:
                 call("ivit_linear_i8_qkv_planned", self.plan(p + "attn.qkv"), P(ws["a8"]), P(ws["q"]), P(ws["k"]),
-                     P(ws["vt"]), B, T, H, dh, ld)
+                     P(ws["vt"]), B, T, H, dh, ldv)
             else:
                 call("ivit_linear_i8_qkv", P(ws["a8"]), self.ptr(p + "attn.qkv.w"), self.ptr(p + "attn.qkv.b"),
                      self.ptr(p + "attn.qkv.dy"), P(ws["q"]), P(ws["k"]), P(ws["vt"]), B, T, H, dh, ld)
             if self.fused_attention:
-                if i in self.rowtab and self.use_exp_tables and self.use_row_tables:
+                if row_attn:
                     call("ivit_attention_fused_rowlut", P(ws["q"]), P(ws["k"]), P(ws["vt"]), _dy(hc[p + "attn.dy_qk"]),
                          f32[p + "attn.s_softmax"], P(self.rowtab[i]), int(hc[p + "attn.exp_meta"][2]),
-                         _dy(hc[p + "attn.dy_pv"]), P(ws["ctx8"]), B, H, T, dh, ld)
+                         _dy(hc[p + "attn.dy_pv"]), P(ws["ctx8"]), B, H, T, dh, ldv)
                 elif p + "attn.exp_meta" in hc and self.use_exp_tables:
                     meta = hc[p + "attn.exp_meta"]
                     call("ivit_attention_fused_lut", P(ws["q"]), P(ws["k"]), P(ws["vt"]), _dy(hc[p + "attn.dy_qk"]),

@@ -101,7 +101,8 @@ int ivit_linear_i8_requant_residual(ivit_handle h, const int8_t *x, const int8_t
 
 /* a1 + a3 + head split (vit_quant.py:61-69): qkv Linear -> QuantAct(8) -> q,k as
  * [B,H,T,dh] and v TRANSPOSED as [B,H,dh,ldv] (token dim contiguous, ldv % 16 == 0,
- * ldv >= T) — the layout the MFMA attn·v operand wants.  x is [B*T, D], w [3D, D].      */
+ * ldv >= T) — the layout the MFMA attn·v operand wants.  x is [B*T, D], w [3D, D].
+ * ldv == 0 (round 6): v ROW-major [B,H,T,dh] like q and k, for ivit_attention_fused_rowlut(ldv = 0). */
 int ivit_linear_i8_qkv(ivit_handle h, const int8_t *x, const int8_t *w, const int32_t *bias,
                        const ivit_dyadic *dy_ch, int8_t *q, int8_t *k, int8_t *vt, int B, int T,
                        int H, int dh, int ldv);
@@ -187,7 +188,9 @@ int ivit_attention_fused_lut(ivit_handle h, const int8_t *q, const int8_t *k, co
  * line does not fit: 1 - dmin > 64; the two-level form then stays); ivit_attention_fused_rowlut is ivit_attention_fused with
  * ONE table gather per score: a wavefront fetches the 16 lines of its query tile once the row maxima are known.  Needs
  * |m 2^-e| < 2^9 for both requant multipliers (IVIT_ERR_UNSUPPORTED otherwise).  Same integers as ivit_attention_fused
- * (vit_quant.py:70-83).                                                                                              */
+ * (vit_quant.py:70-83).
+ * ldv == 0 (this entry point only): `vt` is v ROW-major [B*H, T, dh] — what ivit_linear_i8_qkv / _planned write when THEIR ldv is 0
+ * (one 16-byte store per token and head instead of sixteen byte stores); the kernel transposes on its way into the LDS.      */
 int ivit_shiftmax_rowtable(ivit_handle h, const uint16_t *exp_aq, const float *exp_t, const uint8_t *exp_cls,
                            int nclass, int t_count, int dmin, float *rowtab);
 int ivit_attention_fused_rowlut(ivit_handle h, const int8_t *q, const int8_t *k, const int8_t *vt,

@@ -1096,6 +1096,19 @@ def test_planned_qkv_scatter_vs_numpy(H, B, T, Hh, dh):
     assert np.array_equal(k.cpu().numpy().reshape(B, Hh, T, dh), ref[:, :, 1].transpose(0, 2, 1, 3))
     assert np.array_equal(vt.cpu().numpy().reshape(B, Hh, dh, ld)[..., :T], ref[:, :, 2].transpose(0, 2, 3, 1))
     assert not vt.cpu().numpy().reshape(B, Hh, dh, ld)[..., T:].any()      # the pad stays untouched
+    # round 6: ldv = 0 -> v ROW-major [B,H,T,dh] like q and k (one 16-byte store per lane), planned and unplanned entry points;
+    # one guard row behind the tensor stays untouched
+    for planned in (True, False):
+        vr = torch.full((B * Hh * T + 1, dh), 77, dtype=torch.int8, device="cuda")
+        q.zero_(); k.zero_()
+        if planned:
+            H.call("ivit_linear_i8_qkv_planned", plan.p, P(xd), P(q), P(k), P(vr), B, T, Hh, dh, 0)
+        else:
+            H.call("ivit_linear_i8_qkv", P(xd), P(wd), P(bd), P(d), P(q), P(k), P(vr), B, T, Hh, dh, 0)
+        assert np.array_equal(q.cpu().numpy().reshape(B, Hh, T, dh), ref[:, :, 0].transpose(0, 2, 1, 3))
+        assert np.array_equal(k.cpu().numpy().reshape(B, Hh, T, dh), ref[:, :, 1].transpose(0, 2, 1, 3))
+        assert np.array_equal(vr[:-1].cpu().numpy().reshape(B, Hh, T, dh), ref[:, :, 2].transpose(0, 2, 1, 3)), planned
+        assert (vr[-1] == 77).all()
     plan.close()
 
 
@@ -1573,6 +1586,11 @@ def test_fused_attention_core_vs_oracle(H, T, kind):
     o3 = torch.full_like(o1, 9)
     H.call("ivit_attention_fused_rowlut", P(qd), P(kd), P(vd), dyv(dqk_h), float(scale), P(rt), int(tabs["dmin"]), dyv(dpv_h), P(o3), B, Hh, T, dh, ld)
     assert np.array_equal(o3.cpu().numpy().astype(np.int32), ref), (T, kind, "row tables")
+    o4 = torch.full_like(o1, 9)              # the same with v ROW-major (ldv = 0): transposed inside the kernel
+    H.call("ivit_attention_fused_rowlut", P(qd), P(kd), P(dev(v)), dyv(dqk_h), float(scale), P(rt), int(tabs["dmin"]), dyv(dpv_h), P(o4), B, Hh, T, dh, 0)
+    assert np.array_equal(o4.cpu().numpy().astype(np.int32), ref), (T, kind, "row tables, v row-major")
+    with pytest.raises(_lib.IvitError, match="ldv"):      # the other forms read v^T only
+        H.call("ivit_attention_fused", P(qd), P(kd), P(vd), dyv(dqk_h), float(scale), dyv(dpv_h), P(o1), B, Hh, T, dh, 0)
     assert len(np.unique(ref)) > 10
 
 

@@ -36,13 +36,14 @@ for seed, s, spread in ((0, 0.1947, 30), (1, 0.3036, 30), (2, 0.2508, 30), (3, 0
     if hasattr(iv.freeze, "shiftmax_rowtable"):
         rt = iv.freeze.shiftmax_rowtable(tabs)
         rowtab = dev(rt) if rt is not None else None
-    for name, rtp in (("two-gather", None), ("row lines", rowtab)):
-        if name == "row lines" and rowtab is None:
+    vrow = vt[:, :, :T].transpose(1, 2).contiguous()          # [B*H, T, dh]
+    for name, rtp, vsrc, ldv in (("two-gather", None, vt, ld), ("row lines", rowtab, vt, ld), ("row lines, v row-major", rowtab, vrow, 0)):
+        if name != "two-gather" and rowtab is None:
             continue
         out.zero_()
         us = F(0)
-        rc = probe.attn_probe(P(q), P(k), P(vt), float(dqk[0, 0]), float(dqk[0, 1]), float(s), P(aq), P(et), P(cls), int(tabs["NC"]), int(tabs["t"].size),
-                              int(tabs["dmin"]), P(rtp) if rtp is not None else None, float(dpv[0, 0]), float(dpv[0, 1]), P(out), B, Hh, T, ld, 20, ctypes.byref(us))
+        rc = probe.attn_probe(P(q), P(k), P(vsrc), float(dqk[0, 0]), float(dqk[0, 1]), float(s), P(aq), P(et), P(cls), int(tabs["NC"]), int(tabs["t"].size),
+                              int(tabs["dmin"]), P(rtp) if rtp is not None else None, float(dpv[0, 0]), float(dpv[0, 1]), P(out), B, Hh, T, ldv, 20, ctypes.byref(us))
         torch.cuda.synchronize()
         print(f"s {float(s):.4f} NC {tabs['NC']} NE {tabs['NE']} R {tabs['R']} spread {spread}: library {min(ts):.1f} us | probe {name} {us.value:.1f} us rc {rc} | "
               f"{int((out != ref).sum())} bytes differ", flush=True)

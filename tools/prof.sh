@@ -18,7 +18,7 @@ find $OUT -name "*.csv" | head -30
 python $R/tools/prof_summary.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
 # the default (2 slices, hipGraph) run: timeline coverage and per-kernel durations when slices share the chip
-rocprofv3 --kernel-trace --output-format csv -d $OUT/graph_trace -o g -- python $R/bench.py --steps 12 --warmup 2 --no-cpu-baseline --profile-steps 0 --reps 1 --min-seconds 0 > $OUT/bench_graph_trace.json 2> $OUT/graph_trace.err
+rocprofv3 --kernel-trace --output-format csv -d $OUT/graph_trace -o g -- python $R/bench.py --steps 12 --warmup 2 --no-cpu-baseline --profile-steps 0 --reps 1 --min-seconds 0 --streams 2 --graph 1 > $OUT/bench_graph_trace.json 2> $OUT/graph_trace.err
 python $R/tools/trace_cover.py $OUT/graph_trace > $OUT/sliced_graph_trace.txt 2>&1
 cat $OUT/sliced_graph_trace.txt
 # keep only small artefacts

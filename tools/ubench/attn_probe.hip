@@ -26,6 +26,11 @@ extern "C" int attn_probe(const int8_t *q, const int8_t *k, const int8_t *vt, do
 #ifdef ATT_HAS_ROWTAB
         if (rows) {
             const size_t lds = AttCfg<4>::SMEM + ATT_ROWLINE_BYTES;
+            if (ldv == 0) {      // v row-major
+                (void)hipFuncSetAttribute((const void *)attn_fused_kernel<4, true, 197, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                attn_fused_kernel<4, true, 197, 2, true><<<B * H, ATT_WAVES * 64, lds, 0>>>(a);
+                return;
+            }
             (void)hipFuncSetAttribute((const void *)attn_fused_kernel<4, true, 197, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attn_fused_kernel<4, true, 197, 2><<<B * H, ATT_WAVES * 64, lds, 0>>>(a);
             return;
