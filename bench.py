@@ -249,6 +249,7 @@ def main():
     ap.add_argument("--streams", type=int, default=int(os.environ.get("IVIT_STREAMS", "0")),
                     help="batch slices on the runner's internal HIP streams (0 = per-model default)")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("IVIT_GRAPH", "1")), help="replay a captured hipGraph")
+    ap.add_argument("--box-probe", type=int, default=1, help="0: skip the MFMA / copy probe (profiling runs: keeps its kernels out of the trace)")
     ap.add_argument("--auto-mode", type=int, default=1,
                     help="unless --streams / --graph are given: try (default slices + hipGraph) and (one stream, eager) untimed, time the faster")
     args = ap.parse_args()
@@ -382,7 +383,7 @@ def main():
         ok = bool(np.array_equal(step()[:gb].cpu().numpy(), want))
     all_ranks_exit_unless(ok is not False, "bench.py: logits of the golden prefix differ from the reference's; nothing reported")
 
-    box = box_probe(local_rank) if rank == 0 else None
+    box = box_probe(local_rank) if (rank == 0 and args.box_probe) else None
     # per-operator HIP-event timing (separate instrumented steps, one stream, one C-ABI call per operator)
     per = {}
     if rank == 0 and args.profile_steps > 0:

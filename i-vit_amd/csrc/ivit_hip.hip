@@ -754,9 +754,16 @@ static int launch_attn2(ivit_handle h, const AttnArgs &a, int BH) {
     const size_t lds = AttCfg<NB>::SMEM + (LUT == 2 ? (size_t)ATT_ROWLINE_BYTES
                                                    : (LUT == 1 ? (size_t)((a.t_count + 3) & ~3) * 4 + (size_t)a.nc * 512 + 256 : 0));
     if (lds > 65536) {
-        hipError_t e = hipFuncSetAttribute((const void *)attn_fused_kernel<NB, FAST, TT, LUT, VROW>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { snprintf(h->err, sizeof(h->err), "attn attr: %s", hipGetErrorString(e)); return IVIT_ERR_HIP; }
+        // once per device and instantiation for the largest size seen (the attribute is a maximum): since round 6 every launch of
+        // the row-table form is above 64 KB, and the eager single-stream mode pays host calls
+        static std::atomic<int> set_dev[IVIT_MAX_DEVICES];
+        const bool cached = h->device >= 0 && h->device < IVIT_MAX_DEVICES;
+        if (!cached || set_dev[h->device].load(std::memory_order_acquire) < (int)lds) {
+            hipError_t e = hipFuncSetAttribute((const void *)attn_fused_kernel<NB, FAST, TT, LUT, VROW>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) { snprintf(h->err, sizeof(h->err), "attn attr: %s", hipGetErrorString(e)); return IVIT_ERR_HIP; }
+            if (cached) set_dev[h->device].store((int)lds, std::memory_order_release);
+        }
     }
     attn_fused_kernel<NB, FAST, TT, LUT, VROW><<<BH, ATT_WAVES * 64, lds, h->stream>>>(a);
     hipError_t e = hipGetLastError();

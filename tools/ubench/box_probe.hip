@@ -31,15 +31,16 @@ __global__ __launch_bounds__(256) void box_mfma_kernel(int *out, int n, unsigned
         for (int i = 0; i < 4; ++i)
             for (int r = 0; r < 16; ++r) s += c[i][r];
     } else {
-        v4i c[8];
-        for (int i = 0; i < 8; ++i)
-            for (int r = 0; r < 4; ++r) c[i][r] = 0;
+        v4i c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0, c4 = c0, c5 = c0, c6 = c0, c7 = c0;
+        // eight independent accumulators, the MFMAs as asm statements: through the builtin hipcc rotates the accumulators through
+        // AGPR copies every iteration (7 VALU moves per MFMA) and the loop measures those
+#define BOX_MFMA16(c, x, y) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(c) : "v"(x), "v"(y))
         for (int it = 0; it < n; ++it) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) c[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[i & 3], b[i & 3], c[i], 0, 0, 0);
+            BOX_MFMA16(c0, a[0], b[0]); BOX_MFMA16(c1, a[1], b[1]); BOX_MFMA16(c2, a[2], b[2]); BOX_MFMA16(c3, a[3], b[3]);
+            BOX_MFMA16(c4, b[0], a[0]); BOX_MFMA16(c5, b[1], a[1]); BOX_MFMA16(c6, b[2], a[2]); BOX_MFMA16(c7, b[3], a[3]);
         }
-        for (int i = 0; i < 8; ++i)
-            for (int r = 0; r < 4; ++r) s += c[i][r];
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last MFMAs' results before the compiler's readers
+        for (int r = 0; r < 4; ++r) s += c0[r] + c1[r] + c2[r] + c3[r] + c4[r] + c5[r] + c6[r] + c7[r];
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
