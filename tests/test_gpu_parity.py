@@ -176,6 +176,32 @@ def test_layernorm_golden(H, ops_golden):
         assert np.array_equal(o8.cpu().numpy(), g[f"ln/{i}/out8"]), i
 
 
+@pytest.mark.parametrize("C", [384, 768, 192, 1024])
+def test_layernorm_requant_vs_oracle_ragged(H, C):
+    """I-LayerNorm + per-channel QuantAct(8) against the CPU oracle (quant_modules.py:353-386, quant_utils.py:213-253) on
+    random rows at four channel counts (S = 2 and S = 4 lane splits of layernorm_reg_kernel): row counts that leave dead lane
+    groups in the last wave and the last block, a strided input (the class-token rows of the final norm), scales with both
+    signs, a guard row behind the output.  (Round 6 wrote it for the hand-packed variant of the kernel, which was measured and
+    not kept — tools/experiments/ivit_layernorm_pk.h; the shipped kernel had no oracle test on ragged random rows either.)"""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(C)
+    w = rng.normal(1.0, 0.4, C).astype(np.float32) * rng.choice([-1.0, 1.0], C).astype(np.float32)
+    b = rng.normal(0.0, 0.5, C).astype(np.float32)
+    bias_int, sc = iv.freeze.layernorm_constants(w, b)
+    s_in, s_out = np.float32(7.3e-4), np.float32(0.031)
+    d, dd = dy_dev(sc, s_out)
+    for rows, stride in ((1, C), (7, C), (33, C), (1000, C), (4099, C), (64, 3 * C)):
+        x = rng.integers(-26000, 26000, (rows, stride // C, C)).astype(np.int16)
+        x[:, 0, : C // 2] //= 64                                      # small and large magnitudes in one row
+        want = orc.requant(orc.layernorm(np.ascontiguousarray(x[:, 0]), float(s_in), bias_int, sc), orc.dyadic(sc, s_out), 8)
+        o8 = torch.full((rows + 1, C), 77, dtype=torch.int8, device="cuda")
+        H.call("ivit_layernorm_requant", P(dev(x)), rows, C, stride, float(s_in), P(dev(bias_int)), P(dev(sc)), P(dd), P(o8))
+        got = o8.cpu().numpy()
+        assert np.array_equal(got[:rows].astype(np.int32), want), (C, rows, stride, int((got[:rows] != want).sum()))
+        assert (got[rows] == 77).all()
+        assert len(np.unique(want)) > 50
+
+
 def test_requant_golden(H, ops_golden):
     g = ops_golden
     for i in range(int(g["requant/n"])):
