@@ -1620,10 +1620,13 @@ def test_fused_attention_core_vs_oracle(H, T, kind):
     assert len(np.unique(ref)) > 10
 
 
-@pytest.mark.parametrize("M", [640, 1000])
+@pytest.mark.parametrize("M", [640, 1000, 2 * 256 * 64 + 37, 3 * 256 * 64 + 64 * 5 + 1])
 def test_mlp_fused_vs_oracle(H, M):
     """ivit_mlp_fused against the CPU ORACLE directly (Mlp.forward, layers_quant.py:144-153 + the residual
-    QuantAct of the block): fc1 -> qact(8) -> ShiftGELU -> qact(8) -> fc2 -> qact(16) -> qact(16, + identity)."""
+    QuantAct of the block): fc1 -> qact(8) -> ShiftGELU -> qact(8) -> fc2 -> qact(16) -> qact(16, + identity).
+    640 / 1000 rows run the phase-by-phase kernel; from two 64-token tiles per CU on the role-split
+    swin_mlp_rs_kernel runs: 32 805 rows (two tiles everywhere, a ragged third on one workgroup) and 49 473 (three, and a
+    fourth on five workgroups plus a one-row tile)."""
     from oracle import oracle as orc
     rng = np.random.default_rng(M + 1)
     C, HD = 96, 384
