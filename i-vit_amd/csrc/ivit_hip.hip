@@ -1075,6 +1075,34 @@ int ivit_layernorm_requant(ivit_handle h, const int16_t *x, int64_t rows, int C,
     return IVIT_OK;
 }
 
+// PatchMerging's gather folded into the LayerNorm that follows it (swin_quant.py:336-349: the 2 x 2 gather, norm over 4C, qact1):
+// x int16 [B, R, R, C] -> out8 int8 [B (R/2)^2, 4C].  Same integers as ivit_patch_merge_gather + ivit_layernorm_requant.
+int ivit_patch_merge_layernorm_requant(ivit_handle h, const int16_t *x, int B, int R, int C, float scale, const float *bias_int,
+                                       const float *sc, const ivit_dyadic *dy_ch, int8_t *out8) {
+    CHECK_H(h);
+    REQUIRE(h, x && bias_int && sc && dy_ch && out8 && B > 0 && R > 0 && (R % 2) == 0 && C > 0 && scale > 0.f, "bad arguments");
+    const long long rows = (long long)B * (R / 2) * (R / 2);
+#define LNM_LAUNCH(CC, S)                                                                                                \
+    do {                                                                                                                 \
+        constexpr int rpb = (LNR_THREADS(S) / 64) * (64 / (4 * S));                                                      \
+        layernorm_reg_kernel<CC, S, true><<<(unsigned)((rows + rpb - 1) / rpb), LNR_THREADS(S), 0, h->stream>>>(        \
+            x, rows, 0, scale, bias_int, sc, dy_ch, out8, R);                                                            \
+        LAUNCH_CHECK(h);                                                                                                 \
+        return IVIT_OK;                                                                                                  \
+    } while (0)
+    switch (4 * C) {
+        case 384: LNM_LAUNCH(384, 2);       // Swin-T/S: 96 -> 384
+        case 512: LNM_LAUNCH(512, 4);       // Swin-B: 128 -> 512
+        case 768: LNM_LAUNCH(768, 4);
+        case 1024: LNM_LAUNCH(1024, 4);
+        case 1536: LNM_LAUNCH(1536, 4);
+        default: break;
+    }
+#undef LNM_LAUNCH
+    snprintf(h->err, sizeof(h->err), "%s: built for C = 96, 128, 192, 256, 384 (use ivit_patch_merge_gather + ivit_layernorm_requant)", __func__);
+    return IVIT_ERR_UNSUPPORTED;
+}
+
 // ---------------------------------------------------------------- Swin-specific operators
 int ivit_shiftmax_masked(ivit_handle h, const int8_t *x, int64_t rows, int n, int ld_in, float scale, int out_bits,
                          const float *mask, int nW, int H, uint16_t *out, int ld_out) {

@@ -292,13 +292,18 @@ template <> struct LnRaw<8> { typedef short T __attribute__((ext_vector_type(8))
 template <> struct LnRaw<4> { typedef short T __attribute__((ext_vector_type(4))); };
 template <> struct LnRaw<2> { typedef short T __attribute__((ext_vector_type(2))); };
 
-template <int CC, int S>
+// MERGE_R > 0 (round 6): the row is PatchMerging's 2 x 2 gather (swin_quant.py:336-342) of x [B, R, R, CC / 4] done in the load —
+// merged row (b, yo, xo) = the four tokens (2 yo + (q & 1), 2 xo + (q >> 1)), q = 0..3, side by side in the reference's
+// torch.cat order; a 32-element step never straddles two of them (CC / 4 is a multiple of 32), so a step's quarter is a
+// compile-time number and the gather costs four row offsets per lane instead of a 2 x 77 MB pass of its own
+// (ivit_patch_merge_gather).  `merge_R` = R, `rows` = B (R / 2)^2, `row_stride` unused.
+template <int CC, int S, bool MERGE = false>
 __global__ __launch_bounds__(LNR_THREADS(S), LNR_MIN_WAVES(CC, S)) void layernorm_reg_kernel(const int16_t *__restrict__ x, long long rows,
                                                                      long long row_stride, float s,
                                                                      const float *__restrict__ bias_int,
                                                                      const float *__restrict__ sc,
                                                                      const ivit_dyadic *__restrict__ dy,
-                                                                     int8_t *__restrict__ out) {
+                                                                     int8_t *__restrict__ out, int merge_R = 0) {
 #if !IVIT_PROBE_LN192_S1
     static_assert(S != 1, "the 4-lanes-per-row form is a probe (see the note above)");
 #endif
@@ -314,12 +319,23 @@ __global__ __launch_bounds__(LNR_THREADS(S), LNR_MIN_WAVES(CC, S)) void layernor
     const long long row = live ? row_raw : rows - 1;          // a dead lane group recomputes the last row, stores nothing
     const int16_t *xp = x + row * row_stride + 8 * k + EPC * hh;
     const float ys = rcp_rn(s);
+    const int16_t *xq[4] = {xp, xp, xp, xp};
+    if constexpr (MERGE) {
+        static_assert((CC / 4) % 32 == 0, "a 32-element step lies inside one of the four merged tokens");
+        const int R2 = merge_R >> 1;
+        const long long per = (long long)R2 * R2;
+        const int b = (int)(row / per), rem = (int)(row - (long long)b * per), yo = rem / R2, xo = rem - yo * R2;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            xq[q] = x + ((((long long)b * merge_R + 2 * yo + (q & 1)) * merge_R + 2 * xo + (q >> 1)) * (CC / 4)) + 8 * k + EPC * hh;
+    }
 
     // ---- load, x = fl(fl(Q*s)/s)
     float xv[NSTEP][EPC];
 #pragma unroll
     for (int i = 0; i < NSTEP; ++i) {
-        const typename LnRaw<EPC>::T t = *reinterpret_cast<const typename LnRaw<EPC>::T *>(xp + 32 * i);
+        const int16_t *src = MERGE ? xq[(32 * i) / (CC / 4)] + (32 * i) % (CC / 4) : xp + 32 * i;
+        const typename LnRaw<EPC>::T t = *reinterpret_cast<const typename LnRaw<EPC>::T *>(src);
 #pragma unroll
         for (int e = 0; e < EPC; ++e) xv[i][e] = requotient_m((float)t[e], s, ys);
     }

@@ -354,6 +354,9 @@ struct ivit_swin_s {
     hipEvent_t fork;
 };
 
+#ifndef IVIT_OPT_MERGE_LN
+#define IVIT_OPT_MERGE_LN 1            // A/B: PatchMerging's gather folded into its LayerNorm (ivit_patch_merge_layernorm_requant)
+#endif
 #ifndef IVIT_OPT_SWIN_PLANS
 #define IVIT_OPT_SWIN_PLANS 0          // A/B: the C = 384 / 768 stages' QuantLinear layers on the planned (persistent) kernels
 #endif
@@ -447,11 +450,15 @@ int swin_run_slice(const ivit_swin_s *m, ivit_handle h, const int8_t *images, in
         }
         if (li < c.num_layers - 1) {     // PatchMerging: gather -> LN(4C) -> qact1(8) -> reduction -> qact2(8)
             const ivit_swin_merge &g = m->merges[li];
-            RUN(ivit_patch_merge_gather(h, x, 16, B, res, C, t16));
+            // the 2 x 2 gather rides in the LayerNorm's loads (round 6: as a pass of its own it was 32 us per merge at Swin-T b256)
+            rc = IVIT_OPT_MERGE_LN ? ivit_patch_merge_layernorm_requant(h, x, B, res, C, g.s_in, g.n.bias_int, g.n.sc, g.n.dy, a8) : IVIT_ERR_UNSUPPORTED;
+            const bool merged = rc == IVIT_OK;
+            if (!merged && rc != IVIT_ERR_UNSUPPORTED) RUN(rc);
+            if (!merged) RUN(ivit_patch_merge_gather(h, x, 16, B, res, C, t16));
             res /= 2;
             L = res * res;
             M = (long long)B * L;
-            RUN(swin_ln(m, h, t16, M, 4 * C, g.s_in, g.n, L, false, a8));
+            if (!merged) RUN(swin_ln(m, h, t16, M, 4 * C, g.s_in, g.n, L, false, a8));
             RUN(ivit_linear_i8_requant(h, a8, g.red.w, nullptr, g.red.dy, 8, ctx, (int)M, 2 * C, 4 * C));
             RUN(ivit_widen_i8_i16(h, ctx, x, M * 2 * C));
         }

@@ -453,6 +453,11 @@ int ivit_mlp_fused_planned(ivit_handle h, ivit_mlp_plan p, const int8_t *x, cons
 /* PatchMerging's 2x2 gather (swin_quant.py:336-342): x [B,R,R,C] (in_bits 8 or 16) ->
  * int16 [B, (R/2)^2, 4C], channel blocks in the reference's torch.cat order.                  */
 int ivit_patch_merge_gather(ivit_handle h, const void *x, int in_bits, int B, int R, int C, int16_t *out);
+/* The same gather folded into the I-LayerNorm + QuantAct(8) that follows it in PatchMerging.forward (swin_quant.py:336-349:
+ * gather, self.norm over 4C, qact1) — x int16 [B,R,R,C] -> out8 int8 [B (R/2)^2, 4C]; the gathered tensor never exists.  Same
+ * integers as ivit_patch_merge_gather + ivit_layernorm_requant.  C in {96, 128, 192, 256, 384}; else IVIT_ERR_UNSUPPORTED.      */
+int ivit_patch_merge_layernorm_requant(ivit_handle h, const int16_t *x, int B, int R, int C, float scale,
+                                       const float *bias_int, const float *sc, const ivit_dyadic *dy_ch, int8_t *out8);
 int ivit_widen_i8_i16(ivit_handle h, const int8_t *x, int16_t *out, int64_t n);
 
 /* ---- diagnostics (used by the parity tests only) ------------------------------------

@@ -202,6 +202,36 @@ def test_layernorm_requant_vs_oracle_ragged(H, C):
         assert len(np.unique(want)) > 50
 
 
+@pytest.mark.parametrize("C,R,B", [(96, 56, 3), (192, 28, 5), (384, 14, 9), (128, 8, 2)])
+def test_patch_merge_layernorm_equals_gather_then_layernorm(H, C, R, B):
+    """PatchMerging's 2 x 2 gather folded into the loads of the I-LayerNorm + QuantAct(8) that follows it (swin_quant.py:336-349,
+    round 6) == ivit_patch_merge_gather followed by ivit_layernorm_requant, and == the CPU oracle on the numpy gather."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(C + R)
+    x = rng.integers(-24000, 24000, (B, R, R, C)).astype(np.int16)
+    C4 = 4 * C
+    w = rng.normal(1.0, 0.3, C4).astype(np.float32); b = rng.normal(0.0, 0.4, C4).astype(np.float32)
+    bias_int, sc = iv.freeze.layernorm_constants(w, b)
+    s_in, s_out = np.float32(6.1e-4), np.float32(0.028)
+    d, dd = dy_dev(sc, s_out)
+    rows = B * (R // 2) ** 2
+    xd = dev(x)
+    t16 = torch.empty(rows, C4, dtype=torch.int16, device="cuda")
+    H.call("ivit_patch_merge_gather", P(xd), 16, B, R, C, P(t16))
+    want = torch.empty(rows, C4, dtype=torch.int8, device="cuda")
+    H.call("ivit_layernorm_requant", P(t16), rows, C4, C4, float(s_in), P(dev(bias_int)), P(dev(sc)), P(dd), P(want))
+    got = torch.full((rows + 1, C4), 55, dtype=torch.int8, device="cuda")
+    H.call("ivit_patch_merge_layernorm_requant", P(xd), B, R, C, float(s_in), P(dev(bias_int)), P(dev(sc)), P(dd), P(got))
+    assert torch.equal(got[:rows], want)
+    assert (got[rows] == 55).all()
+    xm = np.concatenate([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], axis=-1).reshape(rows, C4)
+    assert np.array_equal(t16.cpu().numpy(), xm)
+    ref = orc.requant(orc.layernorm(np.ascontiguousarray(xm), float(s_in), bias_int, sc), orc.dyadic(sc, s_out), 8)
+    assert np.array_equal(got[:rows].cpu().numpy().astype(np.int32), ref)
+    with pytest.raises(_lib.IvitError):
+        H.call("ivit_patch_merge_layernorm_requant", P(xd), B, R, 40, float(s_in), P(dev(bias_int)), P(dev(sc)), P(dd), P(got))
+
+
 def test_requant_golden(H, ops_golden):
     g = ops_golden
     for i in range(int(g["requant/n"])):
