@@ -110,11 +110,64 @@ def pmc_traffic():
         return None
 
 
-def pmc_traffic_per_kernel(batch, T, D, Hd):
+def measure_traffic_live(model, timeout_s=150):
+    """HBM bytes per GEMM-class launch measured BY THIS RUN: two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE — the two do not fit one
+    pass on gfx950) of a short single-stream eager forward of this very script, as subprocesses after the timed region.  Collected and
+    corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes: separate --pmc passes, KiB units, FETCH_SIZE doubled (the counter
+    tallies 128-byte requests at 64 B for wide coalesced reads).  Returns the dict of profiles/pmc_traffic.json, or None on any
+    failure (no rocprofv3, a refused counter, a timeout): the caller then prints the committed file and says so."""
+    import csv
+    import glob
+    import re
+    import shutil
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None
+    tmp = tempfile.mkdtemp(prefix="ivit_pmc_", dir="/tmp")
+    cmd_tail = [sys.executable, os.path.abspath(__file__), "--model", model, "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                "--profile-steps", "0", "--streams", "1", "--graph", "0", "--reps", "1", "--min-seconds", "0", "--box-probe", "0",
+                "--measure-traffic", "0"]
+    per = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            r = subprocess.run([rocprof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--"] + cmd_tail,
+                               cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                               timeout=timeout_s)
+            fs = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not fs:
+                return None
+            for row in csv.DictReader(open(fs[0])):
+                if row["Counter_Name"] != counter:
+                    continue
+                name = re.sub(r"\(.*", "", row["Kernel_Name"]).replace("void ", "")[:70]
+                if name.startswith("gemm_") or name.startswith("mlp384"):
+                    per.setdefault(name, {}).setdefault(counter, []).append(float(row["Counter_Value"]))
+        out, tot_b, tot_n = {}, 0.0, 0
+        for k, v in per.items():
+            if "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
+                return None
+            n = len(v["FETCH_SIZE"])
+            fb = sum(v["FETCH_SIZE"]) / n * 1024 * 2
+            wb = sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"]) * 1024
+            out[k] = {"launches": n, "fetch_MB_x2": round(fb / 1e6, 2), "write_MB": round(wb / 1e6, 2)}
+            tot_b += (fb + wb) * n
+            tot_n += n
+        if not tot_n:
+            return None
+        return {"per_kernel": out, "avg_bytes_per_launch": tot_b / tot_n}
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def pmc_traffic_per_kernel(batch, T, D, Hd, per=None):
     """The same per kernel of the GEMM class, next to the algorithmic bytes of that launch (DeiT-S shapes): a class
     average hides one kernel's wasted re-reads behind another's clean stream."""
     try:
-        per = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["per_kernel"]
+        per = per if per is not None else json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["per_kernel"]
     except Exception:
         return None
     M = batch * T
@@ -249,6 +302,8 @@ def main():
     ap.add_argument("--streams", type=int, default=int(os.environ.get("IVIT_STREAMS", "0")),
                     help="batch slices on the runner's internal HIP streams (0 = per-model default)")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("IVIT_GRAPH", "1")), help="replay a captured hipGraph")
+    ap.add_argument("--measure-traffic", type=int, default=1,
+                    help="N = 1: measure roofline.traffic with two rocprofv3 PMC subprocess passes after the timed region (~25 s); 0 / failure: the committed profiles/pmc_traffic.json")
     ap.add_argument("--box-probe", type=int, default=1, help="0: skip the MFMA / copy probe (profiling runs: keeps its kernels out of the trace)")
     ap.add_argument("--auto-mode", type=int, default=1,
                     help="unless --streams / --graph are given: try (default slices + hipGraph) and (one stream, eager) untimed, time the faster")
@@ -384,6 +439,7 @@ def main():
     all_ranks_exit_unless(ok is not False, "bench.py: logits of the golden prefix differ from the reference's; nothing reported")
 
     box = box_probe(local_rank) if (rank == 0 and args.box_probe) else None
+    live = measure_traffic_live(args.model) if (rank == 0 and world == 1 and args.measure_traffic) else None
     # per-operator HIP-event timing (separate instrumented steps, one stream, one C-ABI call per operator)
     per = {}
     if rank == 0 and args.profile_steps > 0:
@@ -482,11 +538,15 @@ def main():
             "bound": "mfma", "achieved": None if achieved is None else round(achieved, 1),
             "peak": INT8_PEAK_TOPS, "unit": "TOP/s",
             "frac": None if achieved is None else round(achieved / INT8_PEAK_TOPS, 4),
-            "traffic": pmc_traffic() if args.model == "deit_small" else None,
-            "traffic_per_kernel": pmc_traffic_per_kernel(batch, cfg.num_tokens, cfg.embed_dim, cfg.hidden_dim) if args.model == "deit_small" else None,
-            "traffic_source": ("profiles/pmc_traffic.json — a COMMITTED rocprofv3 PMC run (tools/prof.sh: bench.py --streams 1 --graph 0, "
-                               "separate FETCH_SIZE / WRITE_SIZE passes, FETCH x2-corrected); not measured by the run that printed this line")
-                              if args.model == "deit_small" else None,
+            "traffic": (round(live["avg_bytes_per_launch"]) if live else (pmc_traffic() if args.model == "deit_small" else None)),
+            "traffic_per_kernel": (pmc_traffic_per_kernel(batch, cfg.num_tokens, cfg.embed_dim, cfg.hidden_dim, live["per_kernel"]) if live and family == "vit"
+                                   else (live["per_kernel"] if live
+                                         else (pmc_traffic_per_kernel(batch, cfg.num_tokens, cfg.embed_dim, cfg.hidden_dim) if args.model == "deit_small" else None))),
+            "traffic_source": ("measured by THIS run: two rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE x2-corrected, WRITE_SIZE) of a 3-forward "
+                               "single-stream eager run of this script, as subprocesses after the timed region; mean per GEMM-class launch") if live
+                              else (("profiles/pmc_traffic.json — a COMMITTED rocprofv3 PMC run (tools/prof.sh: bench.py --streams 1 --graph 0, "
+                                     "separate FETCH_SIZE / WRITE_SIZE passes, FETCH x2-corrected); the live measurement was off or failed")
+                                    if args.model == "deit_small" else None),
             "dominant_kernel": dominant,
             "launches_per_step": g_n, "ms_per_step_in_kernel": round(g_ms, 4),
             "avg_launch_ms": round(g_ms / g_n, 5) if g_n else None,

@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$tag
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile-steps 0 --streams 1 --graph 0 --reps 1 --min-seconds 0 --box-probe 0 "$@" > $OUT/bench.json 2> $OUT/trace.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile-steps 0 --streams 1 --graph 0 --reps 1 --min-seconds 0 --box-probe 0 --measure-traffic 0 "$@" > $OUT/bench.json 2> $OUT/trace.err
 python3 - <<PY
 import csv, glob
 f = glob.glob("$OUT/trace/**/*kernel_stats.csv", recursive=True)[0]

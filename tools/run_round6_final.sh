@@ -8,7 +8,7 @@ bash tools/prof.sh r06f > $O/prof.log 2>&1; tail -5 $O/prof.log
 cp gpurun_out/prof_r06f/pmc_traffic.json $O/pmc_traffic.json 2>/dev/null
 python bench.py > $O/bench_deit_small.json 2> $O/bench_deit_small.err; tail -1 $O/bench_deit_small.json | cut -c1-200
 bash tools/mode_sweep.sh 2 > $O/mode_sweep.txt 2>&1; cat $O/mode_sweep.txt
-for m in deit_tiny deit_base swin_tiny vit_base_384; do python bench.py --model $m --no-cpu-baseline > $O/bench_$m.json 2>/dev/null; tail -1 $O/bench_$m.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$m', d['ms_per_step'], d['value'], d['roofline']['frac'], d['config']['launch_mode_trials'])"; done
+for m in deit_tiny deit_base swin_tiny vit_base_384; do python bench.py --model $m --no-cpu-baseline --measure-traffic 0 > $O/bench_$m.json 2>/dev/null; tail -1 $O/bench_$m.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$m', d['ms_per_step'], d['value'], d['roofline']['frac'], d['config']['launch_mode_trials'])"; done
 python tools/attn_probe.py > $O/attn_probe.txt 2>&1; grep -v amdgpu $O/attn_probe.txt | cut -c1-150
 python tools/qkv_bench.py > $O/qkv_bench.txt 2>&1; grep -v amdgpu $O/qkv_bench.txt
 tools/ubench/valu_rates > $O/valu_rates.txt 2>&1
