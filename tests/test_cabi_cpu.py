@@ -105,3 +105,28 @@ def test_dyadic_edge_cases():
     for (m, r), s in zip(d, [1.0, -0.5, 3e-9, 1e12]):
         assert abs(m) >= 2 ** 30 and abs(m) <= 2 ** 31 and m == int(m)
         assert np.isclose(m * r, np.float64(np.float32(s)) / np.float64(np.float32(0.37)), rtol=1e-9)
+
+
+def test_shiftmax_rowtable_restates_the_two_level_tables():
+    """freeze.shiftmax_rowtable (round 6: one 64-entry line of exp_int per row maximum, the host restatement the GPU tests compare
+    ivit_shiftmax_rowtable with) against the definition of the two-level tables and against the fp32 arithmetic of
+    IntSoftmax.int_exp_shift (quant_modules.py:469-481) for every (row maximum, score) pair, for scales with 1 ... 13 requotient classes;
+    None exactly when a line does not fit 64 entries."""
+    from ivit_amd import freeze
+    for s in (0.3036, 0.2508, 0.2306, 0.1947, 0.52, 0.6203, 0.1059, 0.0902):
+        s = np.float32(s)
+        tabs = freeze.shiftmax_tables(s)
+        assert tabs is not None
+        rt = freeze.shiftmax_rowtable(tabs)
+        if tabs["R"] > 64:
+            assert rt is None
+            continue
+        assert rt.shape == (256, 64) and rt.dtype == np.float32
+        v = np.arange(-128, 128).astype(np.float32)
+        f = ((v * s).astype(np.float32) / s).astype(np.float32)                    # x~(v)
+        dmin, R = int(tabs["dmin"]), int(tabs["R"])
+        for q in range(256):
+            direct = freeze._shift_exp_f32((f[: q + 1] - f[q]).astype(np.float32), s)     # exp_int of every score <= the row maximum
+            dd = np.maximum(np.arange(q + 1) - q, dmin) - dmin
+            assert np.array_equal(rt[q, dd], direct), (float(s), q)
+        assert not rt[:, R:].any()
