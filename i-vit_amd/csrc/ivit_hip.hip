@@ -21,6 +21,7 @@
 #include "ivit_mlp.h"
 #include "ivit_mlp_rs.h"
 #include "ivit_swin_mlp_rs.h"
+#include "ivit_gemm_ws.h"
 
 #define IVIT_MAX_DEVICES 64     // per-device caches of launch attributes (larger ordinals simply do not cache)
 struct ivit_ctx {
@@ -463,6 +464,7 @@ struct ivit_linear_plan_s {
     double *cq;
     void *dummy;
     int pipelined_ok, single_fma_ok;
+    v4i *wf;                    // ivit_linear_plan_prepare_qkv: the weights in gemm_ws_qkv_kernel's fragment order (own allocation), or null
     int device;                 // where `dev` lives: destroy / debug reads run there whatever the caller's current device is
 };
 
@@ -506,6 +508,7 @@ int ivit_linear_plan_create(ivit_handle h, const int8_t *w, const int32_t *bias,
     p->pipelined_ok = !(host_bad & 1);
     p->single_fma_ok = !(host_bad & 2);
     p->device = h->device;
+    p->wf = nullptr;
     *out = p;
     return IVIT_OK;
 }
@@ -515,6 +518,7 @@ int ivit_linear_plan_destroy(ivit_linear_plan p) {
     ivit_device_guard g;
     if (!g.enter(p->device)) return IVIT_ERR_HIP;
     (void)hipFree(p->dev);
+    if (p->wf) (void)hipFree(p->wf);
     delete p;
     return IVIT_OK;
 }
@@ -547,6 +551,47 @@ static inline bool use_gemm3(const ivit_linear_plan_s *pl, const GemmArgs &a, in
     if (epi_bit == 4 && a.N < res_min_n) return false;
     return (on & epi_bit) && pl->pipelined_ok && (a.K % 64) == 0 && a.K >= 320 && (a.N % 16) == 0 && (a.ldc % 16) == 0 &&
            (a.lda % 16) == 0 && (a.ldb % 16) == 0 && a.M >= 128;
+}
+
+// ---- D = 384 qkv on the register-resident-weights kernel (ivit_gemm_ws.h), with or without norm1 in its prologue
+#ifndef IVIT_OPT_QKV_WS
+#define IVIT_OPT_QKV_WS 1               // A/B: ivit_linear_i8_qkv_planned(ldv = 0) on gemm_ws_qkv_kernel where the plan is prepared
+#endif
+static inline bool qkv_ws_ok(const ivit_linear_plan_s *pl, int B, int T, int H, int dh) {
+    return pl->wf && dh == 64 && pl->K == WS_K && pl->N == 3 * H * dh && (long long)B * H * T * 64 < (1ll << 31) && (long long)B * T < (1ll << 26);
+}
+static int launch_qkv_ws(ivit_handle h, const ivit_linear_plan_s *pl, const int8_t *x8, const int16_t *x16, float ln_s,
+                         const float *ln_bias_int, const float *ln_sc, const ivit_dyadic *ln_dy, int8_t *q, int8_t *k, int8_t *v,
+                         int B, int T, int H) {
+    if (h->device != pl->device) { snprintf(h->err, sizeof(h->err), "qkv: plan and handle live on different devices"); return IVIT_ERR_INVALID; }
+    WsArgs a;
+    a.x = x8; a.wf = pl->wf; a.bias = pl->bias_eff; a.cq = pl->cq; a.q = q; a.k = k; a.v = v;
+    a.M = B * T; a.N = pl->N; a.T = T; a.H = H; a.dummy = pl->dummy;
+    a.x16 = x16; a.ln_s = ln_s; a.ln_bias_int = ln_bias_int; a.ln_sc = ln_sc; a.ln_dy = ln_dy; a.trace = nullptr;
+    static std::atomic<bool> attr_dev[IVIT_MAX_DEVICES];
+    const bool cached = h->device >= 0 && h->device < IVIT_MAX_DEVICES;
+    if (!cached || !attr_dev[h->device].load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute((const void *)gemm_ws_qkv_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_SMEM);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)gemm_ws_qkv_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_SMEM);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)gemm_ws_qkv_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_SMEM);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)gemm_ws_qkv_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_SMEM);
+        if (e != hipSuccess) { snprintf(h->err, sizeof(h->err), "qkv attr: %s", hipGetErrorString(e)); return IVIT_ERR_HIP; }
+        if (cached) attr_dev[h->device].store(true, std::memory_order_release);
+    }
+    // one workgroup per CU, each with a contiguous range of 32-token tiles
+    const int ntt = (a.M + 31) / 32;
+    const unsigned grid = (unsigned)(ntt < h->num_cu ? ntt : h->num_cu);
+    const bool fma = pl->single_fma_ok;
+    if (x16) {
+        if (fma) gemm_ws_qkv_kernel<true, true><<<grid, WS_THREADS, WS_SMEM, h->stream>>>(a);
+        else gemm_ws_qkv_kernel<false, true><<<grid, WS_THREADS, WS_SMEM, h->stream>>>(a);
+    } else {
+        if (fma) gemm_ws_qkv_kernel<true, false><<<grid, WS_THREADS, WS_SMEM, h->stream>>>(a);
+        else gemm_ws_qkv_kernel<false, false><<<grid, WS_THREADS, WS_SMEM, h->stream>>>(a);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(h->err, sizeof(h->err), "qkv launch: %s", hipGetErrorString(e)); return IVIT_ERR_HIP; }
+    return IVIT_OK;
 }
 
 template <int EPI>
@@ -629,8 +674,42 @@ int ivit_linear_i8_qkv_planned(ivit_handle h, ivit_linear_plan pl, const int8_t 
     GemmArgs a = linear_args(x, pl->w, pl->bias, B * T, 3 * D, D);
     a.dy_ch = pl->dy; a.q = q; a.k = k; a.vt = vt;
     a.T = T; a.H = H; a.dh = dh; a.ldv = ldv; a.D = D;
+    if (IVIT_OPT_QKV_WS && ldv == 0 && qkv_ws_ok(pl, B, T, H, dh)) return launch_qkv_ws(h, pl, x, nullptr, 0.f, nullptr, nullptr, nullptr, q, k, vt, B, T, H);
     if (use_gemm3(pl, a, 2) && (long long)B * T < (1 << 23)) return launch_gemm3<EPI_QKV>(h, pl, a);
     return ivit_linear_i8_qkv(h, x, pl->w, pl->bias, pl->dy, q, k, vt, B, T, H, dh, ldv);
+}
+
+int ivit_linear_plan_prepare_qkv(ivit_handle h, ivit_linear_plan pl) {
+    CHECK_H(h);
+    REQUIRE(h, pl, "null plan");
+    REQUIRE(h, h->device == pl->device, "plan and handle live on different devices");
+    if (pl->wf) return IVIT_OK;
+    if (pl->K != WS_K || pl->N % 192 != 0 || pl->N > WS_MAXN || !pl->pipelined_ok) {
+        snprintf(h->err, sizeof(h->err), "%s: built for K = 384, N a multiple of 192 up to %d, |(acc + bias) * c| < 2^31", __func__, WS_MAXN);
+        return IVIT_ERR_UNSUPPORTED;
+    }
+    v4i *wf = nullptr;
+    hipError_t e = hipMalloc((void **)&wf, (size_t)pl->N * WS_K);
+    if (e != hipSuccess) { snprintf(h->err, sizeof(h->err), "%s: hipMalloc: %s", __func__, hipGetErrorString(e)); return IVIT_ERR_HIP; }
+    ws_swizzle_kernel<<<64, 256, 0, h->stream>>>(pl->w, wf, pl->N);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);       // plan preparation is a build-time call
+    if (e != hipSuccess) { (void)hipFree(wf); snprintf(h->err, sizeof(h->err), "%s: %s", __func__, hipGetErrorString(e)); return IVIT_ERR_HIP; }
+    pl->wf = wf;
+    return IVIT_OK;
+}
+
+int ivit_layernorm_linear_i8_qkv_planned(ivit_handle h, ivit_linear_plan pl, const int16_t *x16, float scale, const float *bias_int,
+                                         const float *sc, const ivit_dyadic *ln_dy, int8_t *q, int8_t *k, int8_t *v, int B, int T,
+                                         int H, int dh) {
+    CHECK_H(h);
+    REQUIRE(h, pl && x16 && bias_int && sc && ln_dy && q && k && v && B > 0 && T > 0 && H > 0 && dh > 0, "bad arguments");
+    REQUIRE(h, pl->N == 3 * H * dh && pl->K == H * dh, "plan shape is not [3*H*dh, H*dh]");
+    if (!qkv_ws_ok(pl, B, T, H, dh)) {
+        snprintf(h->err, sizeof(h->err), "%s: needs ivit_linear_plan_prepare_qkv on a K = 384, dh = 64 plan and B*H*T*64 < 2^31", __func__);
+        return IVIT_ERR_UNSUPPORTED;
+    }
+    return launch_qkv_ws(h, pl, nullptr, x16, scale, bias_int, sc, ln_dy, q, k, v, B, T, H);
 }
 
 }  // extern "C"

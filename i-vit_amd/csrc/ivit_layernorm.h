@@ -153,10 +153,12 @@ struct LnGroup {
     // cb0 = 8 k + EPC h: this lane's first channel of every 32-element step; op = out + row * CC + cb0
     // DMA_SYNC: the constants arrive by LDS-DMA (planned kernel): wait for them — this wave's own transfers by vmcnt, the other
     // waves' by the barrier — in front of the output pass, the first reader
-    template <typename DMA_SYNC = std::false_type>
+    // OP: int8_t * (the row's bytes go to op + 32 i, global memory), or a callable op(i, pk0, pk1) that places step i's
+    // EPC bytes itself (ivit_gemm_ws.h: the consumer's LDS image)
+    template <typename DMA_SYNC = std::false_type, typename OP = int8_t *>
     static __device__ __forceinline__ void run(float (&xv)[NSTEP][EPC], int j, int k, int cb0, bool fastrq, bool live,
                                                const double *cC, const float *cB, const float *cSc, const float *cY,
-                                               const float *bias_int, const float *sc, const ivit_dyadic *dy, int8_t *op,
+                                               const float *bias_int, const float *sc, const ivit_dyadic *dy, OP op,
                                                DMA_SYNC = DMA_SYNC{}) {
         // ---- first sum
         float a0[EPC], a1[EPC];
@@ -252,7 +254,9 @@ struct LnGroup {
                     pk[e >> 2] |= ((unsigned)v & 0xffu) << (8 * (e & 3));
                 }
             }
-            if (live) {
+            if constexpr (!std::is_pointer<OP>::value) {
+                if (live) op(i, pk[0], pk[1]);
+            } else if (live) {
                 if constexpr (EPC == 8) *reinterpret_cast<v2i *>(op + 32 * i) = v2i{(int)pk[0], (int)pk[1]};
                 else if constexpr (EPC == 4) *reinterpret_cast<unsigned *>(op + 32 * i) = pk[0];
                 else *reinterpret_cast<unsigned short *>(op + 32 * i) = (unsigned short)pk[0];

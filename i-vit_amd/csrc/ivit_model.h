@@ -33,6 +33,9 @@ struct ivit_graph_s {
 #ifndef IVIT_OPT_V_ROWMAJOR
 #define IVIT_OPT_V_ROWMAJOR 1          // A/B: v row-major between the qkv GEMM and the row-table attention
 #endif
+#ifndef IVIT_OPT_LN_QKV
+#define IVIT_OPT_LN_QKV 1              // A/B: norm1 inside the qkv GEMM's prologue (ivit_layernorm_linear_i8_qkv_planned) where v is row-major
+#endif
 #ifndef IVIT_OPT_ATTN_ROWTAB
 #define IVIT_OPT_ATTN_ROWTAB 1         // A/B: Shiftmax by row tables (one gather per score) where a layer's table lines fit
 #endif
@@ -96,11 +99,19 @@ int run_slice(const ivit_vit_s *m, ivit_handle h, const int8_t *images, int B, i
     RUN(ivit_embed_finish(h, patch16, P.z_cls, P.pos, P.dy_x, P.dy_pos, x, B, T, D));
     for (int i = 0; i < c.depth; ++i) {
         const ivit_vit_block &b = m->blocks[i];
-        RUN(ivit_layernorm_requant(h, x, M, D, D, b.s_ln1, b.n1_bias_int, b.n1_sc, b.n1_dy, a8));
         // a layer on the row-table attention takes v ROW-major (ldv = 0: the qkv GEMM stores 16 bytes per lane instead of 16 byte
         // stores, the attention kernel transposes on its way into the LDS); the other attention forms read v^T
         const int ldv = (m->fused_attention && m->has_rowtab[i] && IVIT_OPT_V_ROWMAJOR) ? 0 : ld;
-        RUN(ivit_linear_i8_qkv_planned(h, m->plans[4 * i], a8, q, k, vt, B, T, H, dh, ldv));
+        // norm1's 8-bit output has one consumer: where the qkv GEMM keeps a CU's tokens in LDS it is computed there (round 6)
+        rc = (IVIT_OPT_LN_QKV && ldv == 0) ? ivit_layernorm_linear_i8_qkv_planned(h, m->plans[4 * i], x, b.s_ln1, b.n1_bias_int, b.n1_sc, b.n1_dy,
+                                                                                  q, k, vt, B, T, H, dh)
+                                           : IVIT_ERR_UNSUPPORTED;
+        if (rc == IVIT_ERR_UNSUPPORTED) {
+            RUN(ivit_layernorm_requant(h, x, M, D, D, b.s_ln1, b.n1_bias_int, b.n1_sc, b.n1_dy, a8));
+            RUN(ivit_linear_i8_qkv_planned(h, m->plans[4 * i], a8, q, k, vt, B, T, H, dh, ldv));
+        } else {
+            RUN(rc);
+        }
         if (m->fused_attention) {
             if (m->has_rowtab[i])      // one gather per score (round 6)
                 RUN(ivit_attention_fused_rowlut(h, q, k, vt, b.dy_qk, b.s_softmax, m->rowtab + (size_t)i * 256 * 64, b.exp_dmin, b.dy_pv,
@@ -194,6 +205,8 @@ int ivit_vit_create(ivit_handle h, const ivit_vit_config *cfg, const ivit_vit_pa
             ivit_linear_plan pl = nullptr;
             rc = ivit_linear_plan_create(h, lin[k].w, lin[k].bias, lin[k].dy, lin[k].N, lin[k].K, &pl);
             if (rc != IVIT_OK) { ivit_vit_destroy(m); return rc; }
+            // the qkv layer of a D = 384, dh = 64 model also runs on gemm_ws_qkv_kernel (weights in its fragment order)
+            if (k == 0 && IVIT_OPT_LN_QKV && D == WS_K && D / cfg->num_heads == 64) (void)ivit_linear_plan_prepare_qkv(h, pl);
             m->plans.push_back(pl);
         }
         ivit_mlp_plan mp = nullptr;

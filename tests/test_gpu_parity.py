@@ -1168,6 +1168,60 @@ def test_planned_qkv_scatter_vs_numpy(H, B, T, Hh, dh):
     plan.close()
 
 
+@pytest.mark.parametrize("B,T", [(1, 197), (3, 197), (9, 50), (37, 197), (256, 197), (300, 197)])
+def test_layernorm_qkv_fused_vs_oracle(H, B, T):
+    """norm1 + qact1 + attn.qkv of a D = 384 block in one launch (ivit_layernorm_linear_i8_qkv_planned, csrc/ivit_gemm_ws.h;
+    vit_quant.py:136-137 + 65-74) and the qkv layer alone on the same kernel (ivit_linear_i8_qkv_planned, ldv = 0, prepared plan):
+    q, k, v == the CPU oracle's LayerNorm -> QuantAct(8) -> Linear -> QuantAct(8) for the small batches, == the library's two
+    launches on an UNPREPARED plan (gemm_as_kernel) for all of them.  Batches that leave one, several, seven and (B = 300: two
+    panels per workgroup) more than seven 32-token tiles per CU; a ragged last tile everywhere; guard rows behind q, k and v."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(B * 7 + T)
+    D, Hh, dh = 384, 6, 64
+    M = B * T
+    wln = rng.normal(1.0, 0.4, D).astype(np.float32) * rng.choice([-1.0, 1.0], D).astype(np.float32)
+    bln = rng.normal(0.0, 0.5, D).astype(np.float32)
+    bias_int, sc = iv.freeze.layernorm_constants(wln, bln)
+    s_in, s_out = np.float32(7.3e-4), np.float32(0.031)
+    x16 = rng.integers(-26000, 26000, (M, D)).astype(np.int16)
+    x16[:, : D // 2] //= 64
+    w = np.rint(rng.normal(0, 45, (3 * D, D)).clip(-128, 127)).astype(np.int8)
+    b = rng.integers(-2 ** 14, 2 ** 14, 3 * D).astype(np.int32)
+    s_pre = (10 ** rng.uniform(-5.5, -5, 3 * D)).astype(np.float32)
+    s_q = np.float32(0.02)
+    xd, bi_d, sc_d, dln = dev(x16), dev(bias_int), dev(sc), dev(iv.freeze.dyadic(sc, s_out))
+    wd, bd, d = dev(w), dev(b), dev(iv.freeze.dyadic(s_pre, s_q))
+    plain, prepared = H.linear_plan(P(wd), P(bd), P(d), 3 * D, D), H.linear_plan(P(wd), P(bd), P(d), 3 * D, D)
+    H.call("ivit_linear_plan_prepare_qkv", prepared.p)
+    H.call("ivit_linear_plan_prepare_qkv", prepared.p)            # idempotent
+    a8 = torch.empty(M, D, dtype=torch.int8, device="cuda")
+    H.call("ivit_layernorm_requant", P(xd), M, D, D, float(s_in), P(bi_d), P(sc_d), P(dln), P(a8))
+    mk = lambda: [torch.full((B * Hh * T + 1, dh), 77, dtype=torch.int8, device="cuda") for _ in range(3)]
+    ref = mk()
+    H.call("ivit_linear_i8_qkv_planned", plain.p, P(a8), P(ref[0]), P(ref[1]), P(ref[2]), B, T, Hh, dh, 0)
+    if M <= 8000:
+        ln8 = orc.requant(orc.layernorm(x16, float(s_in), bias_int, sc), orc.dyadic(sc, s_out), 8)
+        assert np.array_equal(a8.cpu().numpy().astype(np.int32), ln8)
+        want = orc.requant(orc.linear_i8(ln8.astype(np.int8), w, b), orc.dyadic(s_pre, s_q), 8).reshape(B, T, 3, Hh, dh)
+        for i in range(3):
+            assert np.array_equal(ref[i][:-1].cpu().numpy().reshape(B, Hh, T, dh), want[:, :, i].transpose(0, 2, 1, 3))
+        assert len(np.unique(want)) > 100
+    alone, fused = mk(), mk()
+    H.call("ivit_linear_i8_qkv_planned", prepared.p, P(a8), P(alone[0]), P(alone[1]), P(alone[2]), B, T, Hh, dh, 0)
+    H.call("ivit_layernorm_linear_i8_qkv_planned", prepared.p, P(xd), float(s_in), P(bi_d), P(sc_d), P(dln), P(fused[0]), P(fused[1]), P(fused[2]),
+           B, T, Hh, dh)
+    for i in range(3):
+        assert torch.equal(alone[i], ref[i]), ("qkv on the prepared plan", "qkv"[i], int((alone[i] != ref[i]).sum()))
+        assert torch.equal(fused[i], ref[i]), ("LayerNorm + qkv", "qkv"[i], int((fused[i] != ref[i]).sum()))
+        assert (ref[i][-1] == 77).all() and (fused[i][-1] == 77).all()
+    # a plan that was not prepared, a head dim the kernel is not built for: refused, nothing launched
+    for pl, hh, dd in ((plain, Hh, dh), (prepared, 12, 32)):
+        with pytest.raises(_lib.IvitError, match="prepare_qkv"):
+            H.call("ivit_layernorm_linear_i8_qkv_planned", pl.p, P(xd), float(s_in), P(bi_d), P(sc_d), P(dln), P(fused[0]), P(fused[1]), P(fused[2]),
+                   B, T, hh, dd)
+    plain.close(); prepared.close()
+
+
 def test_linear_plan_bounds_and_fallback(H):
     """the plan proves the pipelined kernel's exactness bounds per channel; a layer outside them (|z*c| may reach 2^31)
     must be routed to the saturating launch-per-tile kernel and still match the oracle."""

@@ -1,239 +1,320 @@
-// ivit_gemm_ws.h — weight-stationary streaming GEMM for the short-K QuantLinear layers
-// (K = 32*KC, KC in {6, 12}: qkv / fc1 of DeiT-T and DeiT-S).
+// ivit_gemm_ws.h — K = 384 QuantLinear (models/quantization_utils/quant_modules.py:21-80, the qkv flavour of
+// models/vit_quant.py:65-74) with the WEIGHTS of a 32-channel tile resident in registers and the tokens of a whole CU in LDS:
 //
-// The LDS-tiled kernel in ivit_gemm2.h moves ~1.4 KB through the LDS per MFMA (two operand
-// fragments read + the DMA that wrote them), which at K = 384 is as much LDS time as MFMA time.
-// Here the WEIGHTS never touch the LDS: a wave keeps its whole 64-channel x K weight panel in
-// registers (2 x KC fragments = 96 VGPRs at K = 384) for the life of the block, and only 32-token
-// activation tiles stream through a 4-deep global_load_lds ring.  Per 32 tokens a wave issues
-// 2*KC MFMAs off KC ds_read_b128 — 0.5 KB of LDS per MFMA and one s_barrier per 2*KC MFMAs.
-// The tile is stored chunk-major ([k/32][token][32 B]): a DMA instruction writes, and a fragment
-// read fetches, one contiguous 1 KB block — conflict-free with no swizzle.
+//   * a workgroup (8 waves, one per CU) owns a contiguous range of 32-token tiles (<= WS_MAXT: 7 x 32 x 384 B = 86 KB of LDS,
+//     loaded once by DMA, [64-column block][token][64 B] with the chunk permutation of ivit_mlp_rs.h);
+//   * a wave's task is (64-channel slab = one head of q, k or v; one half of the CU's token tiles); the 2 x 12 16-byte A
+//     fragments of the slab (24 KB) stay in 96 registers while the wave sweeps its token tiles two at a time (tokens are the
+//     B operand, a lane = a token; each B fragment read from LDS feeds two MFMAs — with one channel tile per wave the LDS read
+//     port is the bound: 4 SIMDs x 1 KB per 32-cycle MFMA = its 128 B/clk), and are replaced fragment by fragment behind the
+//     last sweep's MFMAs: the weights cross L2 -> CU twice per CU and launch;
+//   * NO workgroup barrier after the prologue: the two waves of a SIMD drift into anti-phase (one multiplies while the other
+//     requantises and stores), which is what gemm_as_kernel's per-k-step barrier forbids (profiles/README.md round 6).
 //
-// A block is WS_WAVES (4) waves = 256 channels wide (one wave per SIMD, so three blocks share a CU evenly) and walks a contiguous run of token groups; the grid is
-// (N / 256 panels) x (chunks), sized by the host to one resident round (3 blocks per CU).  Blocks
-// that share a token run sit on the same XCD (same L2).
-//
-// Epilogue (per 32 tokens, straight from the accumulators, under the other waves' MFMAs): the
-// accumulators start at the bias; requant is rne(fl64(z*c)) evaluated as
-// loint(fl64(z*c) + 1.5*2^52) — the same two roundings as the reference's
-// round(z.double()*m.double() / 2^e) (quant_utils.py:229-231), valid while |z*c| < 2^31, which is
-// checked per channel from K and the bias when the constants are staged (else the rint form).
+// v_mfma_i32_32x32x32_i8, the rows of a weight fragment placed so that accumulator register v of lane (token, h) is channel
+// 16 h + v of the tile: 16 consecutive channels per lane, one 16-byte store per token tile.
 #pragma once
-#include "ivit_gemm2.h"
+#include "../../i-vit_amd/csrc/ivit_device.h"
+#include <type_traits>
 
-#define WS_NPANEL 256
-#define WS_NS 4
-// NSUB = 32-channel sub-tiles per wave: 2 -> 4 waves/block, 2 waves/SIMD (256 VGPRs);
-//                                       1 -> 8 waves/block, 4 waves/SIMD (128 VGPRs)
-template <int NSUB> struct WsCfg {
-    static constexpr int WAVES = WS_NPANEL / (32 * NSUB);
-    static constexpr int OCC = NSUB == 2 ? 2 : 4;           // waves per SIMD
-    static constexpr int BLOCKS_PER_CU = 2;
+#define WS_K 384
+#define WS_KS 12                                 // k-steps of 32
+#define WS_MAXT 7                                // 32-token tiles of a panel in LDS
+#define WS_TOK (WS_MAXT * 32)
+#define WS_KBLK (WS_TOK * 64)
+#define WS_SOFF (6 * WS_KBLK)                     // output row offset of each token of the panel (int)
+#define WS_SBIAS (WS_SOFF + WS_TOK * 4)           // the layer's bias (int32 x N) and multipliers (double x N): no vector-memory load
+#define WS_MAXN 1536                             // between two stores of the steady state (loads and stores share vmcnt)
+#define WS_SCQ (WS_SBIAS + WS_MAXN * 4)
+#define WS_SLOCK (WS_SCQ + WS_MAXN * 8)           // one MFMA baton per SIMD
+#define WS_SMEM (WS_SLOCK + 64)
+#define WS_THREADS 512
+#define WS_MAGIC 6755399441055744.0
+#ifndef WS_PRIO
+#define WS_PRIO 0                                // 1: waves 0-3 at priority 3 (static); 2: priority 3 inside the K loop, 0 in the epilogue
+#endif
+#ifndef WS_PIN
+#define WS_PIN 16                                // outputs per scheduling group of the epilogue (4 or 16)
+#endif
+#ifndef WS_FINE
+#define WS_FINE 0
+#endif
+#ifndef WS_TRACE
+#define WS_TRACE 0
+#endif
+#ifndef WS_PF
+#define WS_PF 1                                  // k-steps the B fragments are requested ahead of their MFMAs
+#endif
+#ifndef WS_BATON
+#define WS_BATON 1                               // the two waves of a SIMD take turns in the K loop (one multiplies, the other requantises)
+#endif
+#ifndef WS_ABL
+#define WS_ABL 0                                 // probe builds (results invalid): 1 no epilogue arithmetic, 2 no stores, 4 no MFMAs
+#endif
+
+struct WsArgs {
+    const int8_t *x;          // [M][384]
+    const v4i *wf;            // swizzled weights: fragment (ct * 12 + ks) * 64 + lane
+    const int32_t *bias;      // [N]
+    const double *cq;         // [N]
+    int8_t *q, *k, *v;        // [B*H][T][64] each
+    int M, N, T, H;
+    void *dummy;              // >= 1 KB: where the lanes of rows >= M store
+    long long *trace;         // WS_TRACE builds: [8 waves][32 stamps] of workgroup 0
 };
 
-template <int EPI, int KC, int NSUB>
-__global__ __launch_bounds__(WsCfg<NSUB>::WAVES * 64, WsCfg<NSUB>::OCC) void gemm_ws_kernel(GemmArgs p, int nchunks) {
-    constexpr int STAGE = KC * 1024;
-    constexpr int WAVES = WsCfg<NSUB>::WAVES;
-    __shared__ __attribute__((aligned(16))) char smem[WS_NS * STAGE + WS_NPANEL * 12 + 16];
-    double *sC = reinterpret_cast<double *>(smem + WS_NS * STAGE);
-    int *sBias = reinterpret_cast<int *>(smem + WS_NS * STAGE + WS_NPANEL * 8);
-    int *sFlag = reinterpret_cast<int *>(smem + WS_NS * STAGE + WS_NPANEL * 12);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
-    const int8_t *A = reinterpret_cast<const int8_t *>(p.A);
+__device__ __forceinline__ int ws_chan_of_row(int rho) { return ((rho >> 2) & 1) * 16 + (rho >> 3) * 4 + (rho & 3); }
+__device__ __forceinline__ int ws_g(int tok) { return ((tok >> 1) & 3) ^ ((tok >> 3) & 3) ^ ((tok >> 4) & 1); }
 
-    const int panels = (p.N + WS_NPANEL - 1) / WS_NPANEL;
-    const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
-    const int panel = idx % panels, chunk = xcd + 8 * (idx / panels);
-    const long long G = ((long long)p.M + 31) / 32;
-    const long long g0 = chunk * G / nchunks, g1 = (chunk + 1) * G / nchunks;
-    const int S = (p.dbg & 32) ? 0 : ((p.dbg & 64) ? 2 : (int)(g1 - g0));
-    const int n0 = panel * WS_NPANEL + wave * (32 * NSUB);
-    const int ppw = (KC - wave + WAVES - 1) / WAVES;   // DMA pieces this wave issues per step (wave-uniform)
-
-    if (tid == 0) *sFlag = 0;
-    __syncthreads();
-    if (tid < WS_NPANEL) {
-        const int n = panel * WS_NPANEL + tid;
-        const bool in = n < p.N;
-        const double cv = in ? p.dy_ch[n].m * p.dy_ch[n].r : 0.0;
-        const int bs = (in && p.bias) ? p.bias[n] : 0;
-        sC[tid] = cv;
-        sBias[tid] = bs;
-        // |acc + bias| <= K*2^14 + |bias|; the magic-number rounding needs |z*c| < 2^31
-        const double zmax = (double)p.K * 16384.0 + fabs((double)bs);
-        if (!(fabs(cv) * zmax < 2147483000.0)) atomicOr(sFlag, 1);
+// weights [N][384] -> fragments of 64 lanes x 16 B: fragment ct * 12 + ks, lane l = (row l & 31, k half l >> 5)
+__global__ __launch_bounds__(256) void ws_swizzle_kernel(const int8_t *__restrict__ w, v4i *__restrict__ wf, int N) {
+    const int nfrag = N / 32 * WS_KS;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nfrag * 64; i += gridDim.x * 256) {
+        const int l = i & 63, f = i >> 6, ct = f / WS_KS, ks = f - ct * WS_KS;
+        const int ch = 32 * ct + ws_chan_of_row(l & 31);
+        wf[i] = *reinterpret_cast<const v4i *>(w + (size_t)ch * WS_K + 32 * ks + 16 * (l >> 5));
     }
+}
 
-    auto issue = [&](int s) {
-        const long long t = min((g0 + s) * 32 + l31, (long long)p.M - 1);
-        const int8_t *src = A + t * p.lda + half * 16;
-        char *st = smem + (s % WS_NS) * STAGE;
-#pragma unroll
-        for (int kc0 = 0; kc0 < KC; kc0 += WAVES) {
-            const int kc = kc0 + wave;
-            if (kc >= KC) break;
-            unsigned loff = __builtin_amdgcn_readfirstlane((unsigned)(kc * 1024));
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + kc * 32),
-                                             (__attribute__((address_space(3))) void *)(st + loff), 16, 0, 0);
+template <bool FMA>
+__global__ __launch_bounds__(WS_THREADS, 2) void gemm_ws_qkv_kernel(WsArgs p) {
+    extern __shared__ __attribute__((aligned(256))) char sm[];
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) char lds_c;
+    typedef __attribute__((address_space(3))) v4i lds_v4i;
+    typedef __attribute__((address_space(3))) int lds_i32;
+    typedef __attribute__((address_space(3))) v2d lds_v2d;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned sm_lds = (unsigned)(size_t)(lds_c *)sm;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, tok = lane & 31, kh = lane >> 5, e = kh ^ ws_g(tok);
+    if (WS_PRIO == 1 && wave < 4) __builtin_amdgcn_s_setprio(3);
+    int n_stamp = 0;
+    auto stamp = [&]() __attribute__((always_inline)) {
+        if (WS_TRACE) {
+            if (blockIdx.x == WS_TRACE - 1 && (threadIdx.x & 63) == 0 && n_stamp < 64) p.trace[wave * 64 + n_stamp] = __builtin_readcyclecounter();
+            ++n_stamp;
         }
     };
-    for (int s = 0; s < WS_NS - 1 && s < S; ++s) issue(s);   // first tiles fly while the weights load
-    // the wave's weight panel: fragment (j, kc) = channels n0 + 32j + (lane & 31), k = 32kc + 16*half ..+16
-    v4i w[NSUB][KC];
-#pragma unroll
-    for (int j = 0; j < NSUB; ++j) {
-        const int row = n0 + 32 * j + l31;
-        const int8_t *wp = p.B + (long long)min(row, p.N - 1) * p.ldb + half * 16;
-#pragma unroll
-        for (int kc = 0; kc < KC; ++kc) {
-            v4i v = *reinterpret_cast<const v4i *>(wp + kc * 32);
-            w[j][kc] = row < p.N ? v : v4i{0, 0, 0, 0};
-        }
+    stamp();
+
+    const int ntt = (p.M + 31) >> 5;
+    const int t_beg = (int)((long long)ntt * blockIdx.x / gridDim.x), t_end = (int)((long long)ntt * (blockIdx.x + 1) / gridDim.x);
+    const int ncp = p.N >> 6, ncp3 = ncp / 3;                 // 64-channel slabs; per q | k | v
+    for (int i = tid; i < p.N; i += WS_THREADS) {
+        reinterpret_cast<int *>(sm + WS_SBIAS)[i] = p.bias[i];
+        reinterpret_cast<double *>(sm + WS_SCQ)[i] = p.cq[i];
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // weights and the first WS_NS-1 tiles have landed
+    const unsigned lane16 = lane * 16;
+    if (tid < 16) reinterpret_cast<int *>(sm + WS_SLOCK)[tid] = 0;
+    const unsigned lock = sm_lds + WS_SLOCK + (wave & 3) * 4;
+    auto baton_take = [&]() __attribute__((always_inline)) {
+        unsigned v, one = 1, tmp;
+        unsigned long long save;
+        asm volatile("s_mov_b64 %2, exec\n\t"
+                     "s_mov_b64 exec, 1\n"
+                     ".Lbt%=:\n\t"
+                     "ds_wrxchg_rtn_b32 %0, %3, %4\n\t"
+                     "s_waitcnt lgkmcnt(0)\n\t"
+                     "v_readfirstlane_b32 %1, %0\n\t"
+                     "s_cmp_eq_u32 %1, 0\n\t"
+                     "s_cbranch_scc1 .Lbd%=\n\t"
+                     "s_sleep 2\n\t"
+                     "s_branch .Lbt%=\n"
+                     ".Lbd%=:\n\t"
+                     "s_mov_b64 exec, %2"
+                     : "=&v"(v), "=&s"(tmp), "=&s"(save) : "v"(lock), "v"(one) : "memory", "scc");
+    };
+    auto baton_give = [&]() __attribute__((always_inline)) {
+        unsigned zero = 0;
+        unsigned long long save;
+        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_write_b32 %1, %2\n\ts_mov_b64 exec, %0" : "=&s"(save) : "v"(lock), "v"(zero) : "memory");
+    };
 
-    __syncthreads();
-    const bool fastrq = (*sFlag == 0);
-
-    constexpr int OLO = -128, OHI = 127;
-    // output addressing that does not change from step to step: per sub-tile j the 16-channel run this
-    // lane stores (q/k) or its four 4-channel runs (v^T); the token's (image, position) advance by 32
-    long long obase[NSUB] = {};
-    int vsel[NSUB] = {};                  // QKV: 0 = q, 1 = k, 2 = v^T
-    if (EPI == EPI_QKV) {
+    for (int t0 = t_beg; t0 < t_end; t0 += WS_MAXT) {
+        const int n_own = min(WS_MAXT, t_end - t0);
+        if (t0 != t_beg) __syncthreads();            // a later panel: every wave is done with the previous one
+        // tasks: (slab, token half); half a = tiles [0, na), half b = [na, n_own); a wave's first tasks are of half a
+        const int na = (n_own + 1) >> 1, ntask = n_own > 1 ? 2 * ncp : ncp;
+        // ---- the panel's tokens: global -> LDS by DMA, 16 tokens x 4 chunk slots per instruction (source chunk = slot ^ g);
+        // half a, the first slab's weights, half b: the first task starts when half a has landed
+        auto dma = [&](int tg) __attribute__((always_inline)) {
+            const int tokl = tg * 16 + (lane >> 2), c = (lane & 3) ^ ws_g(tokl);
+            const long long grow = min((long long)t0 * 32 + tokl, (long long)p.M - 1);
+            const int8_t *src = p.x + grow * WS_K + c * 16;
 #pragma unroll
-        for (int j = 0; j < NSUB; ++j) {
-            const int ncol0 = n0 + j * 32;
-            if (ncol0 >= 2 * p.D) {
-                vsel[j] = 2;
-                const int within = ncol0 + half * 4 - 2 * p.D;     // + 8g below: same head while dh % 32 == 0
-                const int head = within / p.dh, d0 = within - head * p.dh;
-                obase[j] = ((long long)head * p.dh + d0) * p.ldv;
-            } else {
-                const int gcol = ncol0 + half * 16;
-                const int which = gcol / p.D, within = gcol - which * p.D;
-                const int head = within / p.dh, d0 = within - head * p.dh;
-                vsel[j] = which;
-                obase[j] = (long long)head * p.T * p.dh + d0;
+            for (int kb = 0; kb < 6; ++kb) {
+                const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(kb * WS_KBLK + tg * 1024));
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + kb * 64),
+                                                 (__attribute__((address_space(3))) void *)(sm + dst), 16, 0, 0);
             }
-        }
-    }
-    int tb = 0, tt = 0;                   // image index and position of token g0*32 + l31
-    if (EPI == EPI_QKV) {
-        const long long t0 = g0 * 32 + l31;
-        tb = (int)(t0 / p.T);
-        tt = (int)(t0 - (long long)tb * p.T);
-    }
-    for (int s = 0; s < S; ++s) {
-        // loads of step s were issued WS_NS-1 steps ago; PPW younger loads per later step.  Stores of the
-        // previous epilogue are younger still: ignoring them only makes the wait longer, never shorter.
-        const int later = min(S - 1 - s, WS_NS - 2);
-        switch (later * ppw) {
-            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-            default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;   // 3 x 2
-        }
-        if (!(p.dbg & 8)) __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (s + WS_NS - 1 < S && !(p.dbg & 4)) issue(s + WS_NS - 1);
-
-        v16i acc[NSUB];
-#pragma unroll
-        for (int j = 0; j < NSUB; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const v4i b4 = *reinterpret_cast<const v4i *>(sBias + wave * (32 * NSUB) + j * 32 + g * 8 + half * 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[j][g * 4 + e] = b4[e];
-            }
-        const char *st = smem + (s % WS_NS) * STAGE + lane * 16;
-        // fragments in batches of AB (all 12 at 2 waves/SIMD; 6 at 4 waves/SIMD, where registers are short
-        // and the other waves cover the second batch's latency): the MFMAs of a batch run back to back
-        constexpr int AB = NSUB == 2 ? KC : KC / 2;
-#pragma unroll
-        for (int k0 = 0; k0 < KC; k0 += AB) {
-            v4i a[AB];
-#pragma unroll
-            for (int kc = 0; kc < AB; ++kc) a[kc] = *reinterpret_cast<const v4i *>(st + (k0 + kc) * 1024);
-            if (p.dbg & 16) {
-#pragma unroll
-                for (int kc = 0; kc < AB; ++kc) acc[0][kc] ^= a[kc][0] ^ a[kc][1] ^ a[kc][2] ^ a[kc][3];
-            } else {
-#pragma unroll
-                for (int kc = 0; kc < AB; ++kc) {
-#pragma unroll
-                    for (int j = 0; j < NSUB; ++j)
-                        acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w[j][k0 + kc], a[kc], acc[j], 0, 0, 0);
-                }
-            }
-        }
-        if (p.dbg & 1) {   // ablation: main loop only
-            int sx = 0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sx ^= acc[0][r] ^ acc[NSUB - 1][r];
-            if (sx == 0x12345678) reinterpret_cast<int *>(p.out)[tid] = sx;
-            continue;
-        }
-
-        // ---- epilogue for tokens (g0+s)*32 + (lane & 31)
-        const long long grow = (g0 + s) * 32 + l31;
-        auto epilogue = [&](auto fast) {
-#pragma unroll
-        for (int j = 0; j < NSUB; ++j) {
-            unsigned W[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int cl = wave * (32 * NSUB) + j * 32 + g * 8 + half * 4;
-                int o[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const double t = (double)acc[j][g * 4 + e] * sC[cl + e];
-                    const int v = decltype(fast)::value ? __double2loint(t + 6755399441055744.0) : (int)__builtin_rint(t);
-                    o[e] = min(max(v, OLO), OHI);
-                }
-                unsigned w01 = __builtin_amdgcn_perm((unsigned)o[1], (unsigned)o[0], 0x0c0c0400u);
-                unsigned w23 = __builtin_amdgcn_perm((unsigned)o[3], (unsigned)o[2], 0x0c0c0400u);
-                W[g] = __builtin_amdgcn_perm(w23, w01, 0x05040100u);
-            }
-            const int ncol0 = n0 + j * 32;                 // this sub-tile's first channel
-            if (EPI == EPI_QKV && vsel[j] == 2) {
-                // v^T rows are token-contiguous: 32 lanes = 32 consecutive tokens -> byte stores
-                if (grow < p.M && ncol0 < p.N) {
-                    int8_t *dst0 = p.vt + (long long)tb * p.H * p.dh * p.ldv + obase[j] + tt;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        int8_t *dst = dst0 + (long long)(g * 8) * p.ldv;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) dst[(long long)e * p.ldv] = (int8_t)(W[g] >> (8 * e));
-                    }
-                }
-                continue;
-            }
-            // half-wave exchange: lanes < 32 end with channels 0..15 of the sub-tile, lanes >= 32 with 16..31
-            auto s02 = __builtin_amdgcn_permlane32_swap(W[0], W[2], false, false);
-            auto s13 = __builtin_amdgcn_permlane32_swap(W[1], W[3], false, false);
-            const v4i v = {(int)s02[0], (int)s02[1], (int)s13[0], (int)s13[1]};
-            const int gcol = ncol0 + half * 16;
-            if (grow < p.M && gcol < p.N) {
-                if (EPI == EPI_QKV) {
-                    int8_t *dst = (vsel[j] == 0 ? p.q : p.k) + ((long long)tb * p.H * p.T + tt) * p.dh + obase[j];
-                    *reinterpret_cast<v4i *>(dst) = v;
-                } else {
-                    *reinterpret_cast<v4i *>(reinterpret_cast<int8_t *>(p.out) + grow * p.ldc + gcol) = v;
-                }
-            }
-        }
         };
-        if (fastrq) epilogue(std::true_type{});
-        else epilogue(std::false_type{});
-        if (EPI == EPI_QKV) {             // next step: 32 tokens on (T >= 32: at most one image boundary)
-            tt += 32;
-            if (tt >= p.T) { tt -= p.T; ++tb; }
+        auto w_load = [&](const char *slab, int f) __attribute__((always_inline)) {      // fragment f of a slab (uniform base + lane offset)
+            return *reinterpret_cast<const v4i *>(slab + lane16 + f * 1024);
+        };
+        auto slab_of = [&](int task) { return reinterpret_cast<const char *>(p.wf + (size_t)(task >= ncp ? task - ncp : task) * 2 * WS_KS * 64); };
+        if (wave < 2 * na) dma(wave);                                   // na <= 4: at most one group per wave
+        v4i W[2][WS_KS];
+        {
+            const char *wq = slab_of(wave < ntask ? wave : 0);
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int ks = 0; ks < WS_KS; ++ks) W[c][ks] = w_load(wq, c * WS_KS + ks);
         }
+        const bool dma_b = 2 * na + wave < 2 * n_own;                   // n_own - na <= 3: at most one group per wave
+        if (dma_b) dma(2 * na + wave);
+        // output row offset of every token of the panel: (b * H * T + t_in_image) * 64
+        if (tid < WS_TOK) {
+            const int row = min(t0 * 32 + tid, p.M - 1), b = row / p.T;
+            reinterpret_cast<int *>(sm + WS_SOFF)[tid] = (b * p.H * p.T + (row - b * p.T)) * 64;
+        }
+        if (dma_b) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    // everything but this wave's six half-b instructions
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        stamp();
+
+        const unsigned fa0 = sm_lds + tok * 64 + e * 16, fa1 = sm_lds + tok * 64 + (e ^ 2) * 16;
+        // The K loop of a sweep: NT token tiles x 2 channel tiles, B fragments WS_PF steps ahead
+        auto mfma_part = [&](auto nt_c, const int tb, const int chb, v16i(&acc)[2][2]) __attribute__((always_inline)) {
+            constexpr int NT = decltype(nt_c)::value;
+            v4i bf[WS_PF + 1][NT];
+            const unsigned fb0 = fa0 + tb * 2048, fb1 = fa1 + tb * 2048;
+            stamp();
+            auto load_b = [&](int ks, int slot) __attribute__((always_inline)) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    bf[slot][t] = *(lds_v4i *)(size_t)(((ks & 1) ? fb1 : fb0) + (ks >> 1) * WS_KBLK + t * 2048);
+            };
+#pragma unroll
+            for (int i = 0; i < WS_PF; ++i) load_b(i, i);
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const v4i b4 = *(lds_v4i *)(size_t)(sm_lds + WS_SBIAS + (chb + 32 * c + 4 * q4) * 4);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) { acc[c][t][4 * q4] = b4[0]; acc[c][t][4 * q4 + 1] = b4[1]; acc[c][t][4 * q4 + 2] = b4[2]; acc[c][t][4 * q4 + 3] = b4[3]; }
+                }
+            if (WS_BATON) baton_take();
+#pragma unroll
+            for (int ks = 0; ks < WS_KS; ++ks) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (WS_FINE && (ks & 3) == 0 && ks) stamp();
+                if (ks + WS_PF < WS_KS) load_b(ks + WS_PF, (ks + WS_PF) % (WS_PF + 1));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        if (!(WS_ABL & 4)) acc[c][t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(W[c][ks], bf[ks % (WS_PF + 1)][t], acc[c][t], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (WS_BATON) baton_give();
+            stamp();
+        };
+        // requant to 8 bits: fma(z, c, magic + 128) leaves Q + 128 in the low dword; the two packs saturate to [0, 255] =
+        // clamp(Q, -128, 127) + 128; the xor takes the bias off again.  One (channel tile, token tile) at a time: sixteen
+        // channels of a token per lane, one 16-byte store
+        auto epi_part = [&](auto nt_c, const int tb, const int chb, int8_t *obase, v16i(&acc)[2][2]) __attribute__((always_inline)) {
+            constexpr int NT = decltype(nt_c)::value;
+            int toff[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) toff[t] = *(lds_i32 *)(size_t)(sm_lds + WS_SOFF + ((tb + t) * 32 + tok) * 4);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                v2d cqv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) cqv[j] = *(lds_v2d *)(size_t)(sm_lds + WS_SCQ + (chb + 32 * c + 2 * j) * 8);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    v4i o4;
+                    if (WS_PIN == 64) {
+                        // staged by hand: eight conversions, eight FMAs, the packs — an instruction's operands are several
+                        // instructions old (the compiler's own order puts each pack right behind the FMAs it reads)
+#pragma unroll
+                        for (int h8 = 0; h8 < 2; ++h8) {
+                            double d[8];
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) d[i] = (double)acc[c][t][8 * h8 + i];
+                            asm volatile("" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]));
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) {
+                                const double m = cqv[4 * h8 + (i >> 1)][i & 1];
+                                d[i] = FMA ? __builtin_fma(d[i], m, WS_MAGIC + 128.0) : (d[i] * m + (WS_MAGIC + 128.0));
+                            }
+                            asm volatile("" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]));
+                            unsigned pk[4], sb[4];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) asm volatile("v_cvt_pk_i16_i32 %0, %1, %2" : "=v"(pk[i]) : "v"(__double2loint(d[2 * i])), "v"(__double2loint(d[2 * i + 1])));
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) asm volatile("v_sat_pk_u8_i16 %0, %1" : "=v"(sb[i]) : "v"(pk[i]));
+#pragma unroll
+                            for (int i = 0; i < 2; ++i) o4[2 * h8 + i] = (int)(__builtin_amdgcn_perm(sb[2 * i + 1], sb[2 * i], 0x05040100u) ^ 0x80808080u);
+                        }
+                        asm volatile("" : "+v"(o4));
+                    } else {
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        int o[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const double m = cqv[2 * q4 + (i >> 1)][i & 1];
+                            const double tq = FMA ? __builtin_fma((double)acc[c][t][4 * q4 + i], m, WS_MAGIC + 128.0)
+                                                  : ((double)acc[c][t][4 * q4 + i] * m + (WS_MAGIC + 128.0));
+                            o[i] = (WS_ABL & 1) ? acc[c][t][4 * q4 + i] : __double2loint(tq);
+                        }
+                        unsigned p01, p23, b01, b23;
+                        asm("v_cvt_pk_i16_i32 %0, %1, %2" : "=v"(p01) : "v"(o[0]), "v"(o[1]));
+                        asm("v_cvt_pk_i16_i32 %0, %1, %2" : "=v"(p23) : "v"(o[2]), "v"(o[3]));
+                        asm("v_sat_pk_u8_i16 %0, %1" : "=v"(b01) : "v"(p01));
+                        asm("v_sat_pk_u8_i16 %0, %1" : "=v"(b23) : "v"(p23));
+                        o4[q4] = (int)(__builtin_amdgcn_perm(b23, b01, 0x05040100u) ^ 0x80808080u);
+                        if (WS_PIN == 4) asm volatile("" : "+v"(o4[q4]));
+                    }
+                    if (WS_PIN == 16) asm volatile("" : "+v"(o4));       // pinned per tile: left alone, the optimiser converts every accumulator first
+                    }
+                    const int row = (t0 + tb + t) * 32 + tok;
+                    if (WS_ABL & 2) asm volatile("" ::"v"(o4));
+                    else *reinterpret_cast<v4i *>(row < p.M ? obase + toff[t] + 32 * c : (int8_t *)p.dummy + lane16) = o4;
+                }
+                if (WS_FINE) stamp();
+            }
+        };
+        // One task.  Its last K loop is followed by the NEXT task's weights into the same registers (one unconditional block per
+        // iteration: inside the sweep-shape branches the compiler copies all 96 registers at the back edge), then by its epilogue
+        auto do_task = [&](const int task) __attribute__((always_inline)) {
+            const int half = task >= ncp, cp = task - half * ncp;
+            const int te = half ? n_own : na;
+            int tb = half ? na : 0;
+            const int chb = 64 * cp + 16 * kh;
+            const int which = cp / ncp3;
+            int8_t *obase = (which == 0 ? p.q : which == 1 ? p.k : p.v) + (size_t)(cp - which * ncp3) * p.T * 64 + 16 * kh;
+            v16i acc[2][2];
+            if (te - tb > 2) {
+                mfma_part(std::integral_constant<int, 2>{}, tb, chb, acc);
+                epi_part(std::integral_constant<int, 2>{}, tb, chb, obase, acc);
+                tb += 2;
+            }
+            const bool two = te - tb == 2;
+            if (two) mfma_part(std::integral_constant<int, 2>{}, tb, chb, acc);
+            else mfma_part(std::integral_constant<int, 1>{}, tb, chb, acc);
+            {
+                const char *wn = slab_of(task + 8 < ntask ? task + 8 : task);
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int ks = 0; ks < WS_KS; ++ks) W[c][ks] = w_load(wn, c * WS_KS + ks);
+            }
+            if (two) epi_part(std::integral_constant<int, 2>{}, tb, chb, obase, acc);
+            else epi_part(std::integral_constant<int, 1>{}, tb, chb, obase, acc);
+        };
+        if (wave < ntask) do_task(wave);
+        // half b: every wave's DMA has landed by now (its own: vmcnt below — the weights requested inside the first task retire first)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int task = wave + 8; task < ntask; task += 8) do_task(task);
+        stamp();
     }
 }
