@@ -113,25 +113,20 @@ __global__ __launch_bounds__(WS_THREADS, 2) void gemm_ws_qkv_kernel(WsArgs p) {
             typedef LnGroup<WS_K, 2> G;
             const int j = lane & 7, k = j >> 1, hh = j & 1;
             const float ys = rcp_rn(p.ln_s);
-            // the rows of pass n + 1 are requested before pass n is computed: two waves per SIMD do not hide a load by themselves
-            typedef LnRaw<4>::T raw_t;
-            raw_t raw[G::NSTEP];
-            auto request = [&](int r0) __attribute__((always_inline)) {
-                const long long row_raw = (long long)t0 * 32 + r0 + (lane >> 3);
-                const int16_t *xp = p.x16 + min(row_raw, (long long)p.M - 1) * WS_K + 8 * k + 4 * hh;
-#pragma unroll
-                for (int i = 0; i < G::NSTEP; ++i) raw[i] = *reinterpret_cast<const raw_t *>(xp + 32 * i);
-            };
-            request(wave * 8);
+            // (the phase is VALU-issue-bound like layernorm_reg_kernel itself: requesting pass n + 1's rows ahead, or two rows per lane
+            // group for more independent chains, measured 53.5 / 54.4 us against 51.3 for this form)
             for (int r0 = wave * 8; r0 < n_own * 32; r0 += 64) {
                 const int tokl = r0 + (lane >> 3);
-                const bool live = (long long)t0 * 32 + tokl < p.M;
+                const long long row_raw = (long long)t0 * 32 + tokl;
+                const bool live = row_raw < p.M;
+                const int16_t *xp = p.x16 + (live ? row_raw : (long long)p.M - 1) * WS_K + 8 * k + 4 * hh;
                 float xv[G::NSTEP][G::EPC];
 #pragma unroll
-                for (int i = 0; i < G::NSTEP; ++i)
+                for (int i = 0; i < G::NSTEP; ++i) {
+                    const LnRaw<4>::T t = *reinterpret_cast<const LnRaw<4>::T *>(xp + 32 * i);
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) xv[i][c] = requotient_m((float)raw[i][c], p.ln_s, ys);
-                if (r0 + 64 < n_own * 32) request(r0 + 64);
+                    for (int c = 0; c < 4; ++c) xv[i][c] = requotient_m((float)t[c], p.ln_s, ys);
+                }
                 const unsigned rowa = sm_lds + tokl * 64 + (k & 1) * 8 + 4 * hh, gk = (unsigned)((k >> 1) ^ ws_g(tokl));
                 G::run(xv, j, k, 8 * k + 4 * hh, ln_fast, live, cC, cB, cSc, cY, p.ln_bias_int, p.ln_sc, p.ln_dy,
                        [&](int i, unsigned pk0, unsigned) __attribute__((always_inline)) {

@@ -125,6 +125,8 @@ class ViTEngine:
         # and whose requant multipliers are in the kernel's fast range — the per-operator path makes the runner's choice
         self.use_row_tables = True
         self.v_row_major = True         # forward_ops: v row-major into the row-table attention (False: v^T as before)
+        self.fuse_ln_qkv = True         # forward_ops: norm1 in the qkv GEMM's prologue where the plan is prepared (False: two launches)
+        self._qkv_prepared = set()
         self.rowtab = {}
         if self.fused_attention:
             for i in range(cfg.depth):
@@ -161,6 +163,9 @@ class ViTEngine:
             p = f"blocks.{i}."
             for name, N, K in ((p + "attn.qkv", 3 * D, D), (p + "attn.proj", D, D), (p + "mlp.fc1", Hd, D), (p + "mlp.fc2", D, Hd)):
                 self._plans[name] = self.h.linear_plan(self.ptr(name + ".w"), self.ptr(name + ".b"), self.ptr(name + ".dy"), N, K)
+                if name.endswith("attn.qkv") and D == 384 and D // cfg.num_heads == 64 and \
+                        self.h.lib.ivit_linear_plan_prepare_qkv(self.h.h, self._plans[name].p) == 0:
+                    self._qkv_prepared.add(name)       # gemm_ws_qkv_kernel's weight order: ldv = 0 calls and the fused norm1 form use it
             mp = _P()
             if self.h.lib.ivit_mlp_plan_create(self.h.h, self._plans[p + "mlp.fc1"].p, self._plans[p + "mlp.fc2"].p, ctypes.byref(mp)) == 0:
                 self._mlp_plans[i] = mp
@@ -322,12 +327,18 @@ class ViTEngine:
              _dy(hc["embed.dy_pos"]), P(x), B, T, D)
         for i in range(cfg.depth):
             p = f"blocks.{i}."
-            call("ivit_layernorm_requant", P(x), M, D, D, f32[p + "ln1.s"], self.ptr(p + "norm1.bias_int"),
-                 self.ptr(p + "norm1.sc"), self.ptr(p + "norm1.dy"), P(ws["a8"]))
             # the runner's choice (csrc/ivit_model.h): v ROW-major (ldv = 0) between the planned qkv GEMM and the row-table attention
             row_attn = self.fused_attention and i in self.rowtab and self.use_exp_tables and self.use_row_tables
             ldv = 0 if (row_attn and self.use_plans and self.v_row_major) else ld
-            if self.use_plans:
+            # ... and norm1 inside that GEMM's prologue where its plan is prepared (D = 384, dh = 64: ivit_layernorm_linear_i8_qkv_planned)
+            fused_ln = ldv == 0 and self.fuse_ln_qkv and (p + "attn.qkv") in self._qkv_prepared
+            if not fused_ln:
+                call("ivit_layernorm_requant", P(x), M, D, D, f32[p + "ln1.s"], self.ptr(p + "norm1.bias_int"),
+                     self.ptr(p + "norm1.sc"), self.ptr(p + "norm1.dy"), P(ws["a8"]))
+            if fused_ln:
+                call("ivit_layernorm_linear_i8_qkv_planned", self.plan(p + "attn.qkv"), P(x), f32[p + "ln1.s"], self.ptr(p + "norm1.bias_int"),
+                     self.ptr(p + "norm1.sc"), self.ptr(p + "norm1.dy"), P(ws["q"]), P(ws["k"]), P(ws["vt"]), B, T, H, dh)
+            elif self.use_plans:
                 call("ivit_linear_i8_qkv_planned", self.plan(p + "attn.qkv"), P(ws["a8"]), P(ws["q"]), P(ws["k"]),
                      P(ws["vt"]), B, T, H, dh, ldv)
             else:

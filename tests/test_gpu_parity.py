@@ -450,6 +450,13 @@ def test_vit_forward_golden_logits(fname):
     assert np.array_equal(eng.head_scale(), g["logits_scale"])
     # one C-ABI call per operator from Python: same integers
     assert np.array_equal(eng.forward_ops(d_imgs).cpu().numpy(), g["logits_int"])
+    if fname == "deit_small_b4.npz":
+        # round 6: the D = 384, dh = 64 model takes norm1 inside the qkv GEMM's prologue; the two-launch form gives the same integers
+        assert eng._qkv_prepared and eng.fuse_ln_qkv
+        eng.fuse_ln_qkv = False
+        assert np.array_equal(eng.forward_ops(d_imgs).cpu().numpy(), g["logits_int"])
+    else:
+        assert not eng._qkv_prepared
 
 
 @pytest.mark.parametrize("fname,batch,nslices", [("deit_tiny_b1.npz", 5, 2), ("micro_vit2h_b3.npz", 7, 3),
