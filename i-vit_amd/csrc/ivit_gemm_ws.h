@@ -52,8 +52,15 @@ struct WsArgs {
     float ln_s;
     const float *ln_bias_int, *ln_sc;
     const ivit_dyadic *ln_dy;
+    // EPI = WS_EPI_RES16 (attn.proj + qact2 with the identity branch, vit_quant.py:137-138 + quant_utils.py:238-244): out16 [M][N]
+    // = clamp16(rq(residual, cr) + rq(clamp16(rq(acc + bias, cq)), cm)); cm, cr = m * 2^-e of the two dyadic multipliers, |.| < 2^9
+    const int16_t *residual;
+    int16_t *out16;
+    double cm, cr;
     long long *trace;
 };
+#define WS_EPI_QKV8 0
+#define WS_EPI_RES16 1
 
 __device__ __forceinline__ int ws_chan_of_row(int rho) { return ((rho >> 2) & 1) * 16 + (rho >> 3) * 4 + (rho & 3); }
 __device__ __forceinline__ int ws_g(int tok) { return ((tok >> 1) & 3) ^ ((tok >> 3) & 3) ^ ((tok >> 4) & 1); }
@@ -68,8 +75,9 @@ __global__ __launch_bounds__(256) void ws_swizzle_kernel(const int8_t *__restric
     }
 }
 
-template <bool FMA, bool LN>
+template <bool FMA, bool LN, int EPI = WS_EPI_QKV8>
 __global__ __launch_bounds__(WS_THREADS, 2) void gemm_ws_qkv_kernel(WsArgs p) {
+    static_assert(!(LN && EPI != WS_EPI_QKV8), "norm1 feeds the qkv layer only");
     extern __shared__ __attribute__((aligned(256))) char sm[];
     typedef double v2d __attribute__((ext_vector_type(2)));
     typedef __attribute__((address_space(3))) char lds_c;
@@ -173,7 +181,7 @@ __global__ __launch_bounds__(WS_THREADS, 2) void gemm_ws_qkv_kernel(WsArgs p) {
                     for (int ks = 0; ks < WS_KS; ++ks) W[c][ks] = *reinterpret_cast<const v4i *>(wq + lane16 + (c * WS_KS + ks) * 1024);
             }
             const int chb = 64 * cp + 16 * kh;
-            const int which = cp / ncp3;
+            const int which = EPI == WS_EPI_QKV8 ? cp / ncp3 : 0;
             int8_t *obase = (which == 0 ? p.q : which == 1 ? p.k : p.v) + (size_t)(cp - which * ncp3) * p.T * 64 + 16 * kh;
             auto sweep = [&](auto nt_c, const int tb) __attribute__((always_inline)) {
                 constexpr int NT = decltype(nt_c)::value;
@@ -190,6 +198,20 @@ __global__ __launch_bounds__(WS_THREADS, 2) void gemm_ws_qkv_kernel(WsArgs p) {
                         bf[slot][t] = *(lds_v4i *)(size_t)(((ks & 1) ? fb1 : fb0) + (ks >> 1) * WS_KBLK + t * 2048);
                 };
                 load_b(0, 0);
+                // EPI_RES16: the identity rows of this sweep, requested in front of its K loop (a vector load issued behind the
+                // previous sweep's stores would wait for them)
+                v4i idr[EPI == WS_EPI_RES16 ? 2 : 1][EPI == WS_EPI_RES16 ? NT : 1][2];
+                if constexpr (EPI == WS_EPI_RES16) {
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            const long long row = min((long long)(t0 + tb + t) * 32 + tok, (long long)p.M - 1);
+                            const int16_t *rp = p.residual + row * p.N + chb + 32 * c;
+                            idr[c][t][0] = *reinterpret_cast<const v4i *>(rp);
+                            idr[c][t][1] = *reinterpret_cast<const v4i *>(rp + 8);
+                        }
+                }
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -220,6 +242,36 @@ __global__ __launch_bounds__(WS_THREADS, 2) void gemm_ws_qkv_kernel(WsArgs p) {
                     for (int j = 0; j < 8; ++j) cqv[j] = *(lds_v2d *)(size_t)(sm_lds + WS_SCQ + (chb + 32 * c + 2 * j) * 8);
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
+                        if constexpr (EPI == WS_EPI_RES16) {
+                            // 16-bit requant, then the residual QuantAct: both terms are integers < 2^31 / 2, their sum is the
+                            // reference's fp64 sum; v_cvt_pk_i16_i32 clamps to 16 bits while packing
+                            v4i o0, o1;
+#pragma unroll
+                            for (int d = 0; d < 8; ++d) {
+                                const unsigned rw = (unsigned)(d < 4 ? idr[c][t][0][d] : idr[c][t][1][d - 4]);
+                                int o[2];
+#pragma unroll
+                                for (int h2 = 0; h2 < 2; ++h2) {
+                                    const int v = 2 * d + h2;
+                                    const double m = cqv[v >> 1][v & 1];
+                                    const double tq = FMA ? __builtin_fma((double)acc[c][t][v], m, WS_MAGIC) : ((double)acc[c][t][v] * m + WS_MAGIC);
+                                    const int t16 = min(max(__double2loint(tq), -32768), 32767);
+                                    const int r = h2 ? ((int)rw >> 16) : (int)(short)(rw & 0xffffu);
+                                    o[h2] = rq_fast(r, p.cr) + rq_fast(t16, p.cm);
+                                }
+                                int pk;
+                                asm("v_cvt_pk_i16_i32 %0, %1, %2" : "=v"(pk) : "v"(o[0]), "v"(o[1]));
+                                if (d < 4) o0[d] = pk; else o1[d - 4] = pk;
+                            }
+                            asm volatile("" : "+v"(o0), "+v"(o1));
+                            const long long row = (long long)(t0 + tb + t) * 32 + tok;
+                            if (row < p.M) {
+                                int16_t *op = p.out16 + row * p.N + chb + 32 * c;
+                                *reinterpret_cast<v4i *>(op) = o0;
+                                *reinterpret_cast<v4i *>(op + 8) = o1;
+                            }
+                            continue;
+                        }
                         v4i o4;
 #pragma unroll
                         for (int q4 = 0; q4 < 4; ++q4) {

@@ -464,7 +464,7 @@ struct ivit_linear_plan_s {
     double *cq;
     void *dummy;
     int pipelined_ok, single_fma_ok;
-    v4i *wf;                    // ivit_linear_plan_prepare_qkv: the weights in gemm_ws_qkv_kernel's fragment order (own allocation), or null
+    v4i *wf;                    // ivit_linear_plan_prepare_ws: the weights in gemm_ws_qkv_kernel's fragment order (own allocation), or null
     int device;                 // where `dev` lives: destroy / debug reads run there whatever the caller's current device is
 };
 
@@ -558,7 +558,7 @@ static inline bool use_gemm3(const ivit_linear_plan_s *pl, const GemmArgs &a, in
 #define IVIT_OPT_QKV_WS 1               // A/B: ivit_linear_i8_qkv_planned(ldv = 0) on gemm_ws_qkv_kernel where the plan is prepared
 #endif
 static inline bool qkv_ws_ok(const ivit_linear_plan_s *pl, int B, int T, int H, int dh) {
-    return pl->wf && dh == 64 && pl->K == WS_K && pl->N == 3 * H * dh && (long long)B * H * T * 64 < (1ll << 31) && (long long)B * T < (1ll << 26);
+    return pl->wf && dh == 64 && pl->K == WS_K && pl->N == 3 * H * dh && pl->N % 192 == 0 && (long long)B * H * T * 64 < (1ll << 31) && (long long)B * T < (1ll << 26);
 }
 static int launch_qkv_ws(ivit_handle h, const ivit_linear_plan_s *pl, const int8_t *x8, const int16_t *x16, float ln_s,
                          const float *ln_bias_int, const float *ln_sc, const ivit_dyadic *ln_dy, int8_t *q, int8_t *k, int8_t *v,
@@ -568,6 +568,7 @@ static int launch_qkv_ws(ivit_handle h, const ivit_linear_plan_s *pl, const int8
     a.x = x8; a.wf = pl->wf; a.bias = pl->bias_eff; a.cq = pl->cq; a.q = q; a.k = k; a.v = v;
     a.M = B * T; a.N = pl->N; a.T = T; a.H = H; a.dummy = pl->dummy;
     a.x16 = x16; a.ln_s = ln_s; a.ln_bias_int = ln_bias_int; a.ln_sc = ln_sc; a.ln_dy = ln_dy; a.trace = nullptr;
+    a.residual = nullptr; a.out16 = nullptr; a.cm = a.cr = 0.0;
     static std::atomic<bool> attr_dev[IVIT_MAX_DEVICES];
     const bool cached = h->device >= 0 && h->device < IVIT_MAX_DEVICES;
     if (!cached || !attr_dev[h->device].load(std::memory_order_acquire)) {
@@ -591,6 +592,34 @@ static int launch_qkv_ws(ivit_handle h, const ivit_linear_plan_s *pl, const int8
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(h->err, sizeof(h->err), "qkv launch: %s", hipGetErrorString(e)); return IVIT_ERR_HIP; }
+    return IVIT_OK;
+}
+
+#ifndef IVIT_OPT_RES_WS
+#define IVIT_OPT_RES_WS 1               // A/B: ivit_linear_i8_requant_residual_planned on gemm_ws_qkv_kernel<.., EPI_RES16> where the plan is prepared
+#endif
+static int launch_res_ws(ivit_handle h, const ivit_linear_plan_s *pl, const int8_t *x8, double cm, double cr, const int16_t *residual,
+                         int16_t *out, int M) {
+    if (h->device != pl->device) { snprintf(h->err, sizeof(h->err), "linear: plan and handle live on different devices"); return IVIT_ERR_INVALID; }
+    WsArgs a;
+    a.x = x8; a.wf = pl->wf; a.bias = pl->bias_eff; a.cq = pl->cq; a.q = a.k = a.v = nullptr;
+    a.M = M; a.N = pl->N; a.T = 1; a.H = 1; a.dummy = pl->dummy;
+    a.x16 = nullptr; a.ln_s = 0.f; a.ln_bias_int = a.ln_sc = nullptr; a.ln_dy = nullptr; a.trace = nullptr;
+    a.residual = residual; a.out16 = out; a.cm = cm; a.cr = cr;
+    static std::atomic<bool> attr_dev[IVIT_MAX_DEVICES];
+    const bool cached = h->device >= 0 && h->device < IVIT_MAX_DEVICES;
+    if (!cached || !attr_dev[h->device].load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute((const void *)gemm_ws_qkv_kernel<true, false, WS_EPI_RES16>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_SMEM);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)gemm_ws_qkv_kernel<false, false, WS_EPI_RES16>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_SMEM);
+        if (e != hipSuccess) { snprintf(h->err, sizeof(h->err), "linear attr: %s", hipGetErrorString(e)); return IVIT_ERR_HIP; }
+        if (cached) attr_dev[h->device].store(true, std::memory_order_release);
+    }
+    const int ntt = (M + 31) / 32;
+    const unsigned grid = (unsigned)(ntt < h->num_cu ? ntt : h->num_cu);
+    if (pl->single_fma_ok) gemm_ws_qkv_kernel<true, false, WS_EPI_RES16><<<grid, WS_THREADS, WS_SMEM, h->stream>>>(a);
+    else gemm_ws_qkv_kernel<false, false, WS_EPI_RES16><<<grid, WS_THREADS, WS_SMEM, h->stream>>>(a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(h->err, sizeof(h->err), "linear launch: %s", hipGetErrorString(e)); return IVIT_ERR_HIP; }
     return IVIT_OK;
 }
 
@@ -659,6 +688,8 @@ int ivit_linear_i8_requant_residual_planned(ivit_handle h, ivit_linear_plan pl, 
     GemmArgs a = linear_args(x, pl->w, pl->bias, M, pl->N, pl->K);
     a.out = out; a.dy_ch = pl->dy; a.dy_main = dy_main; a.dy_res = dy_res; a.residual = residual;
     const bool res_fast = fabs(dy_main.m * dy_main.r) < RQ_FAST_CLIM && fabs(dy_res.m * dy_res.r) < RQ_FAST_CLIM;
+    if (IVIT_OPT_RES_WS && pl->wf && res_fast && pl->K == WS_K && M < (1 << 26))
+        return launch_res_ws(h, pl, x, dy_main.m * dy_main.r, dy_res.m * dy_res.r, residual, out, M);
     if (use_gemm3(pl, a, 4) && res_fast) return launch_gemm3<EPI_RQ16_CH_RES>(h, pl, a);
     return ivit_linear_i8_requant_residual(h, x, pl->w, pl->bias, pl->dy, dy_main, dy_res, residual, out, M, pl->N, pl->K);
 }
@@ -679,13 +710,13 @@ int ivit_linear_i8_qkv_planned(ivit_handle h, ivit_linear_plan pl, const int8_t 
     return ivit_linear_i8_qkv(h, x, pl->w, pl->bias, pl->dy, q, k, vt, B, T, H, dh, ldv);
 }
 
-int ivit_linear_plan_prepare_qkv(ivit_handle h, ivit_linear_plan pl) {
+int ivit_linear_plan_prepare_ws(ivit_handle h, ivit_linear_plan pl) {
     CHECK_H(h);
     REQUIRE(h, pl, "null plan");
     REQUIRE(h, h->device == pl->device, "plan and handle live on different devices");
     if (pl->wf) return IVIT_OK;
-    if (pl->K != WS_K || pl->N % 192 != 0 || pl->N > WS_MAXN || !pl->pipelined_ok) {
-        snprintf(h->err, sizeof(h->err), "%s: built for K = 384, N a multiple of 192 up to %d, |(acc + bias) * c| < 2^31", __func__, WS_MAXN);
+    if (pl->K != WS_K || pl->N % 64 != 0 || pl->N > WS_MAXN || !pl->pipelined_ok) {
+        snprintf(h->err, sizeof(h->err), "%s: built for K = 384, N a multiple of 64 up to %d, |(acc + bias) * c| < 2^31", __func__, WS_MAXN);
         return IVIT_ERR_UNSUPPORTED;
     }
     v4i *wf = nullptr;
@@ -706,7 +737,7 @@ int ivit_layernorm_linear_i8_qkv_planned(ivit_handle h, ivit_linear_plan pl, con
     REQUIRE(h, pl && x16 && bias_int && sc && ln_dy && q && k && v && B > 0 && T > 0 && H > 0 && dh > 0, "bad arguments");
     REQUIRE(h, pl->N == 3 * H * dh && pl->K == H * dh, "plan shape is not [3*H*dh, H*dh]");
     if (!qkv_ws_ok(pl, B, T, H, dh)) {
-        snprintf(h->err, sizeof(h->err), "%s: needs ivit_linear_plan_prepare_qkv on a K = 384, dh = 64 plan and B*H*T*64 < 2^31", __func__);
+        snprintf(h->err, sizeof(h->err), "%s: needs ivit_linear_plan_prepare_ws on a K = 384, dh = 64 plan and B*H*T*64 < 2^31", __func__);
         return IVIT_ERR_UNSUPPORTED;
     }
     return launch_qkv_ws(h, pl, nullptr, x16, scale, bias_int, sc, ln_dy, q, k, v, B, T, H);

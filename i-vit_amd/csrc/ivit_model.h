@@ -36,6 +36,9 @@ struct ivit_graph_s {
 #ifndef IVIT_OPT_LN_QKV
 #define IVIT_OPT_LN_QKV 1              // A/B: norm1 inside the qkv GEMM's prologue (ivit_layernorm_linear_i8_qkv_planned) where v is row-major
 #endif
+#ifndef IVIT_OPT_PROJ_WS
+#define IVIT_OPT_PROJ_WS 1             // A/B: attn.proj + qact2 of a D = 384 block on gemm_ws_qkv_kernel (prepared plan)
+#endif
 #ifndef IVIT_OPT_ATTN_ROWTAB
 #define IVIT_OPT_ATTN_ROWTAB 1         // A/B: Shiftmax by row tables (one gather per score) where a layer's table lines fit
 #endif
@@ -206,7 +209,8 @@ int ivit_vit_create(ivit_handle h, const ivit_vit_config *cfg, const ivit_vit_pa
             rc = ivit_linear_plan_create(h, lin[k].w, lin[k].bias, lin[k].dy, lin[k].N, lin[k].K, &pl);
             if (rc != IVIT_OK) { ivit_vit_destroy(m); return rc; }
             // the qkv layer of a D = 384, dh = 64 model also runs on gemm_ws_qkv_kernel (weights in its fragment order)
-            if (k == 0 && IVIT_OPT_LN_QKV && D == WS_K && D / cfg->num_heads == 64) (void)ivit_linear_plan_prepare_qkv(h, pl);
+            if (k == 0 && IVIT_OPT_LN_QKV && D == WS_K && D / cfg->num_heads == 64) (void)ivit_linear_plan_prepare_ws(h, pl);
+            if (k == 1 && IVIT_OPT_PROJ_WS && D == WS_K) (void)ivit_linear_plan_prepare_ws(h, pl);      // attn.proj + residual on the same kernel
             m->plans.push_back(pl);
         }
         ivit_mlp_plan mp = nullptr;

@@ -164,8 +164,10 @@ class ViTEngine:
             for name, N, K in ((p + "attn.qkv", 3 * D, D), (p + "attn.proj", D, D), (p + "mlp.fc1", Hd, D), (p + "mlp.fc2", D, Hd)):
                 self._plans[name] = self.h.linear_plan(self.ptr(name + ".w"), self.ptr(name + ".b"), self.ptr(name + ".dy"), N, K)
                 if name.endswith("attn.qkv") and D == 384 and D // cfg.num_heads == 64 and \
-                        self.h.lib.ivit_linear_plan_prepare_qkv(self.h.h, self._plans[name].p) == 0:
+                        self.h.lib.ivit_linear_plan_prepare_ws(self.h.h, self._plans[name].p) == 0:
                     self._qkv_prepared.add(name)       # gemm_ws_qkv_kernel's weight order: ldv = 0 calls and the fused norm1 form use it
+                if name.endswith("attn.proj") and D == 384:     # ... and attn.proj + the residual QuantAct (the runner's choice)
+                    self.h.lib.ivit_linear_plan_prepare_ws(self.h.h, self._plans[name].p)
             mp = _P()
             if self.h.lib.ivit_mlp_plan_create(self.h.h, self._plans[p + "mlp.fc1"].p, self._plans[p + "mlp.fc2"].p, ctypes.byref(mp)) == 0:
                 self._mlp_plans[i] = mp

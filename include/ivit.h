@@ -48,7 +48,7 @@ enum {
     IVIT_ERR_NO_DEVICE = 4
 };
 
-/* 100 * major + minor.  103 (round 6): ivit_linear_plan_prepare_qkv, ivit_layernorm_linear_i8_qkv_planned (additions only).
+/* 100 * major + minor.  103 (round 6): ivit_linear_plan_prepare_ws, ivit_layernorm_linear_i8_qkv_planned (additions only).
  * 102 (round 6): ivit_shiftmax_rowtable, ivit_attention_fused_rowlut (additions only).
  * 101 (round 5): ivit_mlp_plan_select; ivit_swin_block / ivit_vit_block carry the optional Shiftmax-table
  * fields exp_* at their END (added in 100 without a bump: a caller compiled against an older layout must be rebuilt).
@@ -140,17 +140,18 @@ int ivit_linear_i8_requant_residual_planned(ivit_handle h, ivit_linear_plan p, c
                                             ivit_dyadic dy_res, const int16_t *residual, int16_t *out, int M);
 int ivit_linear_i8_qkv_planned(ivit_handle h, ivit_linear_plan p, const int8_t *x, int8_t *q, int8_t *k, int8_t *vt,
                                int B, int T, int H, int dh, int ldv);
-/* Round 6: the qkv layer of a D = 384, dh = 64 block on the kernel that keeps a CU's tokens in LDS and a 64-channel slab of
- * weights in registers (csrc/ivit_gemm_ws.h).  ivit_linear_plan_prepare_qkv adds the weights in that kernel's fragment order to
- * a plan (K = 384, N a multiple of 192 up to 1536; IVIT_ERR_UNSUPPORTED otherwise; build-time call, synchronises the handle's
- * stream); ivit_linear_i8_qkv_planned(ldv = 0) then runs on it.
+/* Round 6: K = 384 layers on the kernel that keeps a CU's tokens in LDS and a 64-channel slab of weights in registers
+ * (csrc/ivit_gemm_ws.h).  ivit_linear_plan_prepare_ws adds the weights in that kernel's fragment order to a plan (K = 384, N a
+ * multiple of 64 up to 1536; IVIT_ERR_UNSUPPORTED otherwise; idempotent; build-time call, synchronises the handle's stream).
+ * On a prepared plan ivit_linear_i8_qkv_planned(ldv = 0, dh = 64) and ivit_linear_i8_requant_residual_planned (multipliers in the
+ * fast range) run on it — same bytes as on an unprepared plan.
  * ivit_layernorm_linear_i8_qkv_planned = norm1 + qact1 + attn.qkv of a block in ONE launch (vit_quant.py:136-137, 65-74;
  * quant_modules.py:353-386 + quant_utils.py:213-253 + quant_modules.py:21-80): x16 [B*T, 384] is the block's 16-bit input with
  * per-tensor `scale`, bias_int / sc / ln_dy are ivit_layernorm_requant's arguments for norm1, q / k / v are [B*H, T, 64] each
  * (v ROW-major, the ldv = 0 layout).  The bytes are those of ivit_layernorm_requant followed by ivit_linear_i8_qkv_planned;
  * norm1's 8-bit output never exists in HBM.  IVIT_ERR_UNSUPPORTED (nothing launched) unless the plan is prepared, dh = 64 and
  * B*H*T*64 < 2^31.                                                                                             */
-int ivit_linear_plan_prepare_qkv(ivit_handle h, ivit_linear_plan p);
+int ivit_linear_plan_prepare_ws(ivit_handle h, ivit_linear_plan p);
 int ivit_layernorm_linear_i8_qkv_planned(ivit_handle h, ivit_linear_plan p, const int16_t *x16, float scale,
                                          const float *bias_int, const float *sc, const ivit_dyadic *ln_dy, int8_t *q,
                                          int8_t *k, int8_t *v, int B, int T, int H, int dh);

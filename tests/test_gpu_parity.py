@@ -1199,8 +1199,8 @@ def test_layernorm_qkv_fused_vs_oracle(H, B, T):
     xd, bi_d, sc_d, dln = dev(x16), dev(bias_int), dev(sc), dev(iv.freeze.dyadic(sc, s_out))
     wd, bd, d = dev(w), dev(b), dev(iv.freeze.dyadic(s_pre, s_q))
     plain, prepared = H.linear_plan(P(wd), P(bd), P(d), 3 * D, D), H.linear_plan(P(wd), P(bd), P(d), 3 * D, D)
-    H.call("ivit_linear_plan_prepare_qkv", prepared.p)
-    H.call("ivit_linear_plan_prepare_qkv", prepared.p)            # idempotent
+    H.call("ivit_linear_plan_prepare_ws", prepared.p)
+    H.call("ivit_linear_plan_prepare_ws", prepared.p)            # idempotent
     a8 = torch.empty(M, D, dtype=torch.int8, device="cuda")
     H.call("ivit_layernorm_requant", P(xd), M, D, D, float(s_in), P(bi_d), P(sc_d), P(dln), P(a8))
     mk = lambda: [torch.full((B * Hh * T + 1, dh), 77, dtype=torch.int8, device="cuda") for _ in range(3)]
@@ -1223,9 +1223,43 @@ def test_layernorm_qkv_fused_vs_oracle(H, B, T):
         assert (ref[i][-1] == 77).all() and (fused[i][-1] == 77).all()
     # a plan that was not prepared, a head dim the kernel is not built for: refused, nothing launched
     for pl, hh, dd in ((plain, Hh, dh), (prepared, 12, 32)):
-        with pytest.raises(_lib.IvitError, match="prepare_qkv"):
+        with pytest.raises(_lib.IvitError, match="prepare_ws"):
             H.call("ivit_layernorm_linear_i8_qkv_planned", pl.p, P(xd), float(s_in), P(bi_d), P(sc_d), P(dln), P(fused[0]), P(fused[1]), P(fused[2]),
                    B, T, hh, dd)
+    plain.close(); prepared.close()
+
+
+@pytest.mark.parametrize("M,N", [(1, 384), (197, 384), (591, 384), (7000, 384), (50432, 384), (60000, 384), (1000, 128), (1000, 1536)])
+def test_residual_linear_on_prepared_plan_vs_oracle(H, M, N):
+    """attn.proj + qact2 with the identity branch (vit_quant.py:137-138, quant_utils.py:238-244) of a K = 384 layer on
+    gemm_ws_qkv_kernel<.., EPI_RES16> (ivit_linear_plan_prepare_ws + ivit_linear_i8_requant_residual_planned): == the CPU oracle
+    for the small shapes, == the same call on an unprepared plan for all; ragged last tiles, one to more than seven 32-token
+    tiles per CU (two panels), 2 / 6 / 24 channel slabs, a guard row behind the output."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(M + N)
+    K = 384
+    x = rng.integers(-128, 128, (M, K), dtype=np.int8)
+    w = np.rint(rng.normal(0, 45, (N, K)).clip(-128, 127)).astype(np.int8)
+    b = rng.integers(-2 ** 14, 2 ** 14, N).astype(np.int32)
+    s_pre = (10 ** rng.uniform(-5.5, -5, N)).astype(np.float32)
+    s_mid, s_res, s_out = np.float32(2e-4), np.float32(6.9e-4), np.float32(7.3e-4)
+    res = rng.integers(-30000, 30000, (M, N)).astype(np.int16)
+    xd, wd, bd, rd, d = dev(x), dev(w), dev(b), dev(res), dev(iv.freeze.dyadic(s_pre, s_mid))
+    dm, dr = iv.freeze.dyadic(s_mid, s_out), iv.freeze.dyadic(s_res, s_out)
+    plain, prepared = H.linear_plan(P(wd), P(bd), P(d), N, K), H.linear_plan(P(wd), P(bd), P(d), N, K)
+    H.call("ivit_linear_plan_prepare_ws", prepared.p)
+    outs = []
+    for pl in (plain, prepared):
+        o = torch.full((M + 1, N), 77, dtype=torch.int16, device="cuda")
+        H.call("ivit_linear_i8_requant_residual_planned", pl.p, P(xd), dyv(dm), dyv(dr), P(rd), P(o), M)
+        assert (o[-1] == 77).all()
+        outs.append(o[:-1])
+    assert torch.equal(outs[0], outs[1]), int((outs[0] != outs[1]).sum())
+    if M * N <= 3_000_000:
+        t16 = orc.requant(orc.linear_i8(x, w, b), orc.dyadic(s_pre, s_mid), 16)
+        want = orc.requant(t16, orc.dyadic(s_mid, s_out), 16, res.astype(np.int32), orc.dyadic(s_res, s_out))
+        assert np.array_equal(outs[1].cpu().numpy().astype(np.int32), want)
+        assert len(np.unique(want)) > min(1000, M * N // 4)
     plain.close(); prepared.close()
 
 

@@ -13,6 +13,8 @@ dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
 probe = ctypes.CDLL(os.path.join(ROOT, "tools", "ubench", os.environ.get("WS_PROBE_SO", "libgemm_ws_probe.so")))
 I, V, F = ctypes.c_int, ctypes.c_void_p, ctypes.c_float
 probe.gemm_ws_probe.argtypes = [V] * 7 + [I] * 7 + [ctypes.POINTER(F), I, V, F, V, V, V]
+DB = ctypes.c_double
+probe.gemm_ws_probe_res.argtypes = [V] * 6 + [DB, DB] + [I] * 5 + [ctypes.POINTER(F)]
 def timeit(f, n=10):
     for _ in range(3): f()
     torch.cuda.synchronize()
@@ -59,3 +61,25 @@ for name, B, T, D, Hh in (("deit_small b256", 256, 197, 384, 6), ("b3 (ragged)",
         diff = sum(int((o != r).sum()) for o, r in zip(out, ref))
         line += f" | {'LayerNorm + qkv fused' if mode else 'ws qkv'} {us.value:5.1f} us rc {rc}, {diff} bytes differ"
     print(line + f" | {sat} % saturated, {len(torch.unique(x))} LayerNorm levels", flush=True)
+
+# attn.proj + the residual QuantAct on the same kernel (EPI_RES16) against ivit_linear_i8_requant_residual_planned
+for name, M in (("deit_small b256", 256 * 197), ("b3", 3 * 197), ("b100", 100 * 197)):
+    D = 384
+    x = dev(rng.integers(-128, 128, (M, D), dtype=np.int8))
+    w = dev(np.rint(rng.normal(0, 45, (D, D)).clip(-128, 127)).astype(np.int8))
+    b = dev(rng.integers(-2 ** 14, 2 ** 14, D).astype(np.int32))
+    dnp = iv.freeze.dyadic((10 ** rng.uniform(-5.5, -5, D)).astype(np.float32), np.float32(2e-4))
+    d, cq = dev(dnp), dev(dnp[:, 0] * dnp[:, 1])
+    res = dev(rng.integers(-30000, 30000, (M, D)).astype(np.int16))
+    dm, dr = iv.freeze.dyadic(np.float32(2e-4), np.float32(7.3e-4)), iv.freeze.dyadic(np.float32(6.9e-4), np.float32(7.3e-4))
+    plan = H.linear_plan(P(w), P(b), P(d), D, D)
+    ref = torch.zeros(M, D, dtype=torch.int16, device="cuda"); out = torch.zeros_like(ref)
+    f = lambda: H.call("ivit_linear_i8_requant_residual_planned", plan.p, P(x), _lib.Dyadic(float(dm[0, 0]), float(dm[0, 1])),
+                       _lib.Dyadic(float(dr[0, 0]), float(dr[0, 1])), P(res), P(ref), M)
+    t_lib = timeit(f)
+    us = F(0)
+    rc = probe.gemm_ws_probe_res(P(x), P(w), P(b), P(cq), P(res), P(out), float(dm[0, 0] * dm[0, 1]), float(dr[0, 0] * dr[0, 1]), M, D, 1,
+                                 int(os.environ.get("WS_GRID", "256")), 10, ctypes.byref(us))
+    torch.cuda.synchronize()
+    print(f"proj + residual {name:16s} library {t_lib:5.1f} us | ws {us.value:5.1f} us rc {rc}, {int((out != ref).sum())} values differ, "
+          f"{int(((ref == 32767) | (ref == -32768)).sum()) * 100 // ref.numel()} % saturated, {len(torch.unique(ref))} levels", flush=True)

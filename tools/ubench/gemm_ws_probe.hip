@@ -15,7 +15,7 @@ extern "C" int gemm_ws_probe(const int8_t *x, const int8_t *w, const int32_t *bi
     if (hipMalloc((void **)&wf, (size_t)N * WS_K) != hipSuccess || hipMalloc(&dummy, 4096) != hipSuccess || hipMalloc((void **)&trace, 8 * 64 * 8) != hipSuccess) return 2;
     (void)hipMemset(trace, 0, 8 * 64 * 8);
     ws_swizzle_kernel<<<64, 256>>>(w, wf, N);
-    WsArgs a{x, wf, bias, cq, q, k, v, M, N, T, H, dummy, x16, ln_s, ln_bias_int, ln_sc, ln_dy, trace};
+    WsArgs a{x, wf, bias, cq, q, k, v, M, N, T, H, dummy, x16, ln_s, ln_bias_int, ln_sc, ln_dy, nullptr, nullptr, 0.0, 0.0, trace};
     auto launch = [&]() {
 #define WS_L(F, L) do { (void)hipFuncSetAttribute((const void *)gemm_ws_qkv_kernel<F, L>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_SMEM); \
                         gemm_ws_qkv_kernel<F, L><<<grid, WS_THREADS, WS_SMEM, 0>>>(a); } while (0)
@@ -49,5 +49,40 @@ extern "C" int gemm_ws_probe(const int8_t *x, const int8_t *w, const int32_t *bi
         }
     }
     (void)hipFree(trace); (void)hipFree(dummy); (void)hipFree(wf);
+    return hipDeviceSynchronize() == hipSuccess ? 0 : 4;
+}
+
+// attn.proj + residual QuantAct (EPI_RES16): out16 [M][N]
+extern "C" int gemm_ws_probe_res(const int8_t *x, const int8_t *w, const int32_t *bias, const double *cq, const int16_t *residual, int16_t *out16,
+                                 double cm, double cr, int M, int N, int fma, int grid, int reps, float *us) {
+    if (N % 64 || N > WS_MAXN) return 1;
+    v4i *wf = nullptr;
+    void *dummy = nullptr;
+    if (hipMalloc((void **)&wf, (size_t)N * WS_K) != hipSuccess || hipMalloc(&dummy, 4096) != hipSuccess) return 2;
+    ws_swizzle_kernel<<<64, 256>>>(w, wf, N);
+    WsArgs a{x, wf, bias, cq, nullptr, nullptr, nullptr, M, N, 1, 1, dummy, nullptr, 0.f, nullptr, nullptr, nullptr, residual, out16, cm, cr, nullptr};
+    auto launch = [&]() {
+        if (fma) { (void)hipFuncSetAttribute((const void *)gemm_ws_qkv_kernel<true, false, WS_EPI_RES16>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_SMEM);
+                   gemm_ws_qkv_kernel<true, false, WS_EPI_RES16><<<grid, WS_THREADS, WS_SMEM, 0>>>(a); }
+        else { (void)hipFuncSetAttribute((const void *)gemm_ws_qkv_kernel<false, false, WS_EPI_RES16>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_SMEM);
+               gemm_ws_qkv_kernel<false, false, WS_EPI_RES16><<<grid, WS_THREADS, WS_SMEM, 0>>>(a); }
+    };
+    launch();
+    if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed: %s\n", hipGetErrorString(hipGetLastError())); return 3; }
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    float best = 1e30f;
+    for (int rep = 0; rep < 5; ++rep) {
+        (void)hipEventRecord(e0, 0);
+        for (int r = 0; r < reps; ++r) launch();
+        (void)hipEventRecord(e1, 0);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    *us = best * 1000.f / reps;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(dummy); (void)hipFree(wf);
     return hipDeviceSynchronize() == hipSuccess ? 0 : 4;
 }
