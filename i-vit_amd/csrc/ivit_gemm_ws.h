@@ -57,6 +57,7 @@ struct WsArgs {
     const int16_t *residual;
     int16_t *out16;
     double cm, cr;
+    int8_t *ln_out8;          // EPI_RES16 with LN = true: norm2 + qact3 of out16's rows (ln_s .. ln_dy are norm2's), [M][384]
     long long *trace;
 };
 #define WS_EPI_QKV8 0
@@ -77,7 +78,6 @@ __global__ __launch_bounds__(256) void ws_swizzle_kernel(const int8_t *__restric
 
 template <bool FMA, bool LN, int EPI = WS_EPI_QKV8>
 __global__ __launch_bounds__(WS_THREADS, 2) void gemm_ws_qkv_kernel(WsArgs p) {
-    static_assert(!(LN && EPI != WS_EPI_QKV8), "norm1 feeds the qkv layer only");
     extern __shared__ __attribute__((aligned(256))) char sm[];
     typedef double v2d __attribute__((ext_vector_type(2)));
     typedef __attribute__((address_space(3))) char lds_c;
@@ -110,12 +110,13 @@ __global__ __launch_bounds__(WS_THREADS, 2) void gemm_ws_qkv_kernel(WsArgs p) {
     double *cC = reinterpret_cast<double *>(sm + WS_SLN);
     float *cB = reinterpret_cast<float *>(sm + WS_SLN + WS_K * 8), *cSc = cB + WS_K, *cY = cSc + WS_K;
     bool ln_fast = false;
+    constexpr bool LN_HEAD = LN && EPI == WS_EPI_QKV8, LN_TAIL = LN && EPI == WS_EPI_RES16;
     if constexpr (LN) ln_fast = ln_stage_constants<WS_K, WS_THREADS>(p.ln_bias_int, p.ln_sc, p.ln_dy, cC, cB, cSc, cY);
 
     for (int t0 = t_beg; t0 < t_end; t0 += WS_MAXT) {
         const int n_own = min(WS_MAXT, t_end - t0);
         if (t0 != t_beg) __syncthreads();            // a later panel: every wave is done with the previous one
-        if constexpr (LN) {
+        if constexpr (LN_HEAD) {
             // ---- norm1 + qact1 of the panel's rows into the LDS image: 8 rows per wave and pass, 8 lanes per row, lane (k, h)
             // owns channels 32 i + 8 k + 4 h .. + 3 of every step i — 4 bytes of chunk (i & 1) * 2 + (k >> 1) of K block i >> 1
             typedef LnGroup<WS_K, 2> G;
@@ -302,6 +303,30 @@ __global__ __launch_bounds__(WS_THREADS, 2) void gemm_ws_qkv_kernel(WsArgs p) {
             if (te - tb > 2) { sweep(std::integral_constant<int, 2>{}, tb); tb += 2; }
             if (te - tb == 2) sweep(std::integral_constant<int, 2>{}, tb);
             else sweep(std::integral_constant<int, 1>{}, tb);
+        }
+        if constexpr (LN_TAIL) {
+            // ---- norm2 + qact3 of the panel's rows (vit_quant.py:139-140): every channel of a row was produced by this workgroup;
+            // its stores are complete (vmcnt) and no line of out16 was ever read through this CU's L1, so the rows come back from
+            // the L2 they were just written to.  Same arithmetic as layernorm_reg_kernel<384, 2>, bytes to ln_out8 [M][384]
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            typedef LnGroup<WS_K, 2> G;
+            const int j = lane & 7, k = j >> 1, hh = j & 1;
+            const float ys = rcp_rn(p.ln_s);
+            for (int r0 = wave * 8; r0 < n_own * 32; r0 += 64) {
+                const long long row_raw = (long long)t0 * 32 + r0 + (lane >> 3);
+                const bool live = row_raw < p.M;
+                const long long row = live ? row_raw : (long long)p.M - 1;
+                const int16_t *xp = p.out16 + row * WS_K + 8 * k + 4 * hh;
+                float xv[G::NSTEP][G::EPC];
+#pragma unroll
+                for (int i = 0; i < G::NSTEP; ++i) {
+                    const LnRaw<4>::T t = *reinterpret_cast<const LnRaw<4>::T *>(xp + 32 * i);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) xv[i][c] = requotient_m((float)t[c], p.ln_s, ys);
+                }
+                G::run(xv, j, k, 8 * k + 4 * hh, ln_fast, live, cC, cB, cSc, cY, p.ln_bias_int, p.ln_sc, p.ln_dy, p.ln_out8 + row * WS_K + 8 * k + 4 * hh);
+            }
         }
         stamp();
     }

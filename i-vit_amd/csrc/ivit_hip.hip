@@ -568,7 +568,7 @@ static int launch_qkv_ws(ivit_handle h, const ivit_linear_plan_s *pl, const int8
     a.x = x8; a.wf = pl->wf; a.bias = pl->bias_eff; a.cq = pl->cq; a.q = q; a.k = k; a.v = v;
     a.M = B * T; a.N = pl->N; a.T = T; a.H = H; a.dummy = pl->dummy;
     a.x16 = x16; a.ln_s = ln_s; a.ln_bias_int = ln_bias_int; a.ln_sc = ln_sc; a.ln_dy = ln_dy; a.trace = nullptr;
-    a.residual = nullptr; a.out16 = nullptr; a.cm = a.cr = 0.0;
+    a.residual = nullptr; a.out16 = nullptr; a.cm = a.cr = 0.0; a.ln_out8 = nullptr;
     static std::atomic<bool> attr_dev[IVIT_MAX_DEVICES];
     const bool cached = h->device >= 0 && h->device < IVIT_MAX_DEVICES;
     if (!cached || !attr_dev[h->device].load(std::memory_order_acquire)) {
@@ -599,24 +599,30 @@ static int launch_qkv_ws(ivit_handle h, const ivit_linear_plan_s *pl, const int8
 #define IVIT_OPT_RES_WS 1               // A/B: ivit_linear_i8_requant_residual_planned on gemm_ws_qkv_kernel<.., EPI_RES16> where the plan is prepared
 #endif
 static int launch_res_ws(ivit_handle h, const ivit_linear_plan_s *pl, const int8_t *x8, double cm, double cr, const int16_t *residual,
-                         int16_t *out, int M) {
+                         int16_t *out, int M, float ln_s = 0.f, const float *ln_bias_int = nullptr, const float *ln_sc = nullptr,
+                         const ivit_dyadic *ln_dy = nullptr, int8_t *ln_out8 = nullptr) {
     if (h->device != pl->device) { snprintf(h->err, sizeof(h->err), "linear: plan and handle live on different devices"); return IVIT_ERR_INVALID; }
     WsArgs a;
     a.x = x8; a.wf = pl->wf; a.bias = pl->bias_eff; a.cq = pl->cq; a.q = a.k = a.v = nullptr;
     a.M = M; a.N = pl->N; a.T = 1; a.H = 1; a.dummy = pl->dummy;
-    a.x16 = nullptr; a.ln_s = 0.f; a.ln_bias_int = a.ln_sc = nullptr; a.ln_dy = nullptr; a.trace = nullptr;
-    a.residual = residual; a.out16 = out; a.cm = cm; a.cr = cr;
+    a.x16 = nullptr; a.ln_s = ln_s; a.ln_bias_int = ln_bias_int; a.ln_sc = ln_sc; a.ln_dy = ln_dy; a.trace = nullptr;
+    a.residual = residual; a.out16 = out; a.cm = cm; a.cr = cr; a.ln_out8 = ln_out8;
     static std::atomic<bool> attr_dev[IVIT_MAX_DEVICES];
     const bool cached = h->device >= 0 && h->device < IVIT_MAX_DEVICES;
     if (!cached || !attr_dev[h->device].load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute((const void *)gemm_ws_qkv_kernel<true, false, WS_EPI_RES16>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_SMEM);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void *)gemm_ws_qkv_kernel<false, false, WS_EPI_RES16>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_SMEM);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)gemm_ws_qkv_kernel<true, true, WS_EPI_RES16>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_SMEM);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)gemm_ws_qkv_kernel<false, true, WS_EPI_RES16>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_SMEM);
         if (e != hipSuccess) { snprintf(h->err, sizeof(h->err), "linear attr: %s", hipGetErrorString(e)); return IVIT_ERR_HIP; }
         if (cached) attr_dev[h->device].store(true, std::memory_order_release);
     }
     const int ntt = (M + 31) / 32;
     const unsigned grid = (unsigned)(ntt < h->num_cu ? ntt : h->num_cu);
-    if (pl->single_fma_ok) gemm_ws_qkv_kernel<true, false, WS_EPI_RES16><<<grid, WS_THREADS, WS_SMEM, h->stream>>>(a);
+    if (ln_out8) {
+        if (pl->single_fma_ok) gemm_ws_qkv_kernel<true, true, WS_EPI_RES16><<<grid, WS_THREADS, WS_SMEM, h->stream>>>(a);
+        else gemm_ws_qkv_kernel<false, true, WS_EPI_RES16><<<grid, WS_THREADS, WS_SMEM, h->stream>>>(a);
+    } else if (pl->single_fma_ok) gemm_ws_qkv_kernel<true, false, WS_EPI_RES16><<<grid, WS_THREADS, WS_SMEM, h->stream>>>(a);
     else gemm_ws_qkv_kernel<false, false, WS_EPI_RES16><<<grid, WS_THREADS, WS_SMEM, h->stream>>>(a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(h->err, sizeof(h->err), "linear launch: %s", hipGetErrorString(e)); return IVIT_ERR_HIP; }
@@ -692,6 +698,20 @@ int ivit_linear_i8_requant_residual_planned(ivit_handle h, ivit_linear_plan pl, 
         return launch_res_ws(h, pl, x, dy_main.m * dy_main.r, dy_res.m * dy_res.r, residual, out, M);
     if (use_gemm3(pl, a, 4) && res_fast) return launch_gemm3<EPI_RQ16_CH_RES>(h, pl, a);
     return ivit_linear_i8_requant_residual(h, x, pl->w, pl->bias, pl->dy, dy_main, dy_res, residual, out, M, pl->N, pl->K);
+}
+
+int ivit_linear_i8_requant_residual_layernorm_planned(ivit_handle h, ivit_linear_plan pl, const int8_t *x, ivit_dyadic dy_main,
+                                                      ivit_dyadic dy_res, const int16_t *residual, int16_t *out, int M, float ln_scale,
+                                                      const float *ln_bias_int, const float *ln_sc, const ivit_dyadic *ln_dy,
+                                                      int8_t *ln_out8) {
+    CHECK_H(h);
+    REQUIRE(h, pl && x && out && residual && M > 0 && ln_bias_int && ln_sc && ln_dy && ln_out8, "bad arguments");
+    const bool res_fast = fabs(dy_main.m * dy_main.r) < RQ_FAST_CLIM && fabs(dy_res.m * dy_res.r) < RQ_FAST_CLIM;
+    if (!(pl->wf && res_fast && pl->K == WS_K && pl->N == WS_K && M < (1 << 26))) {
+        snprintf(h->err, sizeof(h->err), "%s: needs ivit_linear_plan_prepare_ws on a 384 x 384 plan and residual multipliers in the fast range", __func__);
+        return IVIT_ERR_UNSUPPORTED;
+    }
+    return launch_res_ws(h, pl, x, dy_main.m * dy_main.r, dy_res.m * dy_res.r, residual, out, M, ln_scale, ln_bias_int, ln_sc, ln_dy, ln_out8);
 }
 
 int ivit_linear_i8_qkv_planned(ivit_handle h, ivit_linear_plan pl, const int8_t *x, int8_t *q, int8_t *k, int8_t *vt,

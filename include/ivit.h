@@ -48,7 +48,8 @@ enum {
     IVIT_ERR_NO_DEVICE = 4
 };
 
-/* 100 * major + minor.  103 (round 6): ivit_linear_plan_prepare_ws, ivit_layernorm_linear_i8_qkv_planned (additions only).
+/* 100 * major + minor.  103 (round 6): ivit_linear_plan_prepare_ws, ivit_layernorm_linear_i8_qkv_planned,
+ * ivit_linear_i8_requant_residual_layernorm_planned (additions only).
  * 102 (round 6): ivit_shiftmax_rowtable, ivit_attention_fused_rowlut (additions only).
  * 101 (round 5): ivit_mlp_plan_select; ivit_swin_block / ivit_vit_block carry the optional Shiftmax-table
  * fields exp_* at their END (added in 100 without a bump: a caller compiled against an older layout must be rebuilt).
@@ -152,6 +153,15 @@ int ivit_linear_i8_qkv_planned(ivit_handle h, ivit_linear_plan p, const int8_t *
  * norm1's 8-bit output never exists in HBM.  IVIT_ERR_UNSUPPORTED (nothing launched) unless the plan is prepared, dh = 64 and
  * B*H*T*64 < 2^31.                                                                                             */
 int ivit_linear_plan_prepare_ws(ivit_handle h, ivit_linear_plan p);
+/* attn.proj + qact2 with the identity branch + norm2 + qact3 of a D = 384 block in ONE launch (vit_quant.py:137-140):
+ * out [M, 384] = ivit_linear_i8_requant_residual_planned's result, ln_out8 [M, 384] = ivit_layernorm_requant(out, ln_scale,
+ * ln_bias_int, ln_sc, ln_dy) — the workgroup that produced a row normalises it.  IVIT_ERR_UNSUPPORTED (nothing launched) unless
+ * the plan is a prepared 384 x 384 one and both residual multipliers are in the fast range (|m * 2^-e| < 2^9).  Measured SLOWER
+ * than the two launches in the DeiT-S forward (profiles/README.md, round 6): the native runner does not use it.            */
+int ivit_linear_i8_requant_residual_layernorm_planned(ivit_handle h, ivit_linear_plan p, const int8_t *x, ivit_dyadic dy_main,
+                                                      ivit_dyadic dy_res, const int16_t *residual, int16_t *out, int M,
+                                                      float ln_scale, const float *ln_bias_int, const float *ln_sc,
+                                                      const ivit_dyadic *ln_dy, int8_t *ln_out8);
 int ivit_layernorm_linear_i8_qkv_planned(ivit_handle h, ivit_linear_plan p, const int16_t *x16, float scale,
                                          const float *bias_int, const float *sc, const ivit_dyadic *ln_dy, int8_t *q,
                                          int8_t *k, int8_t *v, int B, int T, int H, int dh);

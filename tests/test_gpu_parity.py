@@ -1260,6 +1260,23 @@ def test_residual_linear_on_prepared_plan_vs_oracle(H, M, N):
         want = orc.requant(t16, orc.dyadic(s_mid, s_out), 16, res.astype(np.int32), orc.dyadic(s_res, s_out))
         assert np.array_equal(outs[1].cpu().numpy().astype(np.int32), want)
         assert len(np.unique(want)) > min(1000, M * N // 4)
+    # norm2 + qact3 in the tail of the same launch (ivit_linear_i8_requant_residual_layernorm_planned): the 16-bit rows and
+    # ivit_layernorm_requant of them; refused for anything but a prepared 384 x 384 plan
+    wln = rng.normal(1.0, 0.4, K).astype(np.float32) * rng.choice([-1.0, 1.0], K).astype(np.float32)
+    bias_int, sc = iv.freeze.layernorm_constants(wln, rng.normal(0.0, 0.5, K).astype(np.float32))
+    bi_d, sc_d, dln = dev(bias_int), dev(sc), dev(iv.freeze.dyadic(sc, np.float32(0.031)))
+    o16 = torch.full((M + 1, N), 77, dtype=torch.int16, device="cuda")
+    o8 = torch.full((M + 1, N), 77, dtype=torch.int8, device="cuda")
+    args = (P(xd), dyv(dm), dyv(dr), P(rd), P(o16), M, float(s_out), P(bi_d), P(sc_d), P(dln), P(o8))
+    if N == 384:
+        H.call("ivit_linear_i8_requant_residual_layernorm_planned", prepared.p, *args)
+        want8 = torch.empty(M, N, dtype=torch.int8, device="cuda")
+        H.call("ivit_layernorm_requant", P(outs[0]), M, N, N, float(s_out), P(bi_d), P(sc_d), P(dln), P(want8))
+        assert torch.equal(o16[:-1], outs[0]) and torch.equal(o8[:-1], want8), (int((o16[:-1] != outs[0]).sum()), int((o8[:-1] != want8).sum()))
+        assert (o16[-1] == 77).all() and (o8[-1] == 77).all() and len(torch.unique(want8)) > min(100, M)
+    for pl in ((plain,) if N == 384 else (plain, prepared)):
+        with pytest.raises(_lib.IvitError, match="prepare_ws"):
+            H.call("ivit_linear_i8_requant_residual_layernorm_planned", pl.p, *args)
     plain.close(); prepared.close()
 
 
