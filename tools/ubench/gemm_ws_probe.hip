@@ -15,7 +15,7 @@ extern "C" int gemm_ws_probe(const int8_t *x, const int8_t *w, const int32_t *bi
     if (hipMalloc((void **)&wf, (size_t)N * WS_K) != hipSuccess || hipMalloc(&dummy, 4096) != hipSuccess || hipMalloc((void **)&trace, 8 * 64 * 8) != hipSuccess) return 2;
     (void)hipMemset(trace, 0, 8 * 64 * 8);
     ws_swizzle_kernel<<<64, 256>>>(w, wf, N);
-    WsArgs a{x, wf, bias, cq, q, k, v, M, N, T, H, dummy, x16, ln_s, ln_bias_int, ln_sc, ln_dy, nullptr, nullptr, 0.0, 0.0, trace};
+    WsArgs a{x, wf, bias, cq, q, k, v, M, N, T, H, dummy, x16, ln_s, ln_bias_int, ln_sc, ln_dy, nullptr, nullptr, 0.0, 0.0, nullptr, trace};
     auto launch = [&]() {
 #define WS_L(F, L) do { (void)hipFuncSetAttribute((const void *)gemm_ws_qkv_kernel<F, L>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_SMEM); \
                         gemm_ws_qkv_kernel<F, L><<<grid, WS_THREADS, WS_SMEM, 0>>>(a); } while (0)
@@ -60,7 +60,7 @@ extern "C" int gemm_ws_probe_res(const int8_t *x, const int8_t *w, const int32_t
     void *dummy = nullptr;
     if (hipMalloc((void **)&wf, (size_t)N * WS_K) != hipSuccess || hipMalloc(&dummy, 4096) != hipSuccess) return 2;
     ws_swizzle_kernel<<<64, 256>>>(w, wf, N);
-    WsArgs a{x, wf, bias, cq, nullptr, nullptr, nullptr, M, N, 1, 1, dummy, nullptr, 0.f, nullptr, nullptr, nullptr, residual, out16, cm, cr, nullptr};
+    WsArgs a{x, wf, bias, cq, nullptr, nullptr, nullptr, M, N, 1, 1, dummy, nullptr, 0.f, nullptr, nullptr, nullptr, residual, out16, cm, cr, nullptr, nullptr};
     auto launch = [&]() {
         if (fma) { (void)hipFuncSetAttribute((const void *)gemm_ws_qkv_kernel<true, false, WS_EPI_RES16>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_SMEM);
                    gemm_ws_qkv_kernel<true, false, WS_EPI_RES16><<<grid, WS_THREADS, WS_SMEM, 0>>>(a); }
