@@ -193,6 +193,7 @@ SIGNATURES = {
     "ivit_linear_i8_requant_residual_planned": [_P, _P, _P, Dyadic, Dyadic, _P, _P, _I],
     "ivit_linear_i8_qkv_planned": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I],
     "ivit_linear_plan_prepare_ws": [_P, _P],
+    "ivit_layernorm_linear_i8_requant_planned": [_P, _P, _P, _F, _P, _P, _P, _P, _I],
     "ivit_linear_i8_requant_residual_layernorm_planned": [_P, _P, _P, Dyadic, Dyadic, _P, _P, _I, _F, _P, _P, _P, _P],
     "ivit_layernorm_linear_i8_qkv_planned": [_P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I],
     "ivit_bmm_nt_i8": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _L, _L],

@@ -62,6 +62,7 @@ struct WsArgs {
 };
 #define WS_EPI_QKV8 0
 #define WS_EPI_RES16 1
+#define WS_EPI_RQ8 2                             // plain QuantLinear -> QuantAct(8): q = out8 [M][N] row-major (Swin's qkv layer)
 
 __device__ __forceinline__ int ws_chan_of_row(int rho) { return ((rho >> 2) & 1) * 16 + (rho >> 3) * 4 + (rho & 3); }
 __device__ __forceinline__ int ws_g(int tok) { return ((tok >> 1) & 3) ^ ((tok >> 3) & 3) ^ ((tok >> 4) & 1); }
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(WS_THREADS, 2) void gemm_ws_qkv_kernel(WsArgs p) {
     double *cC = reinterpret_cast<double *>(sm + WS_SLN);
     float *cB = reinterpret_cast<float *>(sm + WS_SLN + WS_K * 8), *cSc = cB + WS_K, *cY = cSc + WS_K;
     bool ln_fast = false;
-    constexpr bool LN_HEAD = LN && EPI == WS_EPI_QKV8, LN_TAIL = LN && EPI == WS_EPI_RES16;
+    constexpr bool LN_HEAD = LN && EPI != WS_EPI_RES16, LN_TAIL = LN && EPI == WS_EPI_RES16;
     if constexpr (LN) ln_fast = ln_stage_constants<WS_K, WS_THREADS>(p.ln_bias_int, p.ln_sc, p.ln_dy, cC, cB, cSc, cY);
 
     for (int t0 = t_beg; t0 < t_end; t0 += WS_MAXT) {
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(WS_THREADS, 2) void gemm_ws_qkv_kernel(WsArgs p) {
                     for (int ks = 0; ks < WS_KS; ++ks) W[c][ks] = *reinterpret_cast<const v4i *>(wq + lane16 + (c * WS_KS + ks) * 1024);
             }
             const int chb = 64 * cp + 16 * kh;
-            const int which = EPI == WS_EPI_QKV8 ? cp / ncp3 : 0;
+            const int which = EPI == WS_EPI_QKV8 ? cp / max(ncp3, 1) : 0;
             int8_t *obase = (which == 0 ? p.q : which == 1 ? p.k : p.v) + (size_t)(cp - which * ncp3) * p.T * 64 + 16 * kh;
             auto sweep = [&](auto nt_c, const int tb) __attribute__((always_inline)) {
                 constexpr int NT = decltype(nt_c)::value;
@@ -294,7 +295,11 @@ __global__ __launch_bounds__(WS_THREADS, 2) void gemm_ws_qkv_kernel(WsArgs p) {
                             o4[q4] = hq;
                         }
                         const int row = (t0 + tb + t) * 32 + tok;
-                        *reinterpret_cast<v4i *>(row < p.M ? obase + toff[t] + 32 * c : (int8_t *)p.dummy + lane16) = o4;
+                        if constexpr (EPI == WS_EPI_RQ8) {
+                            if (row < p.M) *reinterpret_cast<v4i *>(p.q + (long long)row * p.N + chb + 32 * c) = o4;
+                        } else {
+                            *reinterpret_cast<v4i *>(row < p.M ? obase + toff[t] + 32 * c : (int8_t *)p.dummy + lane16) = o4;
+                        }
                     }
                 }
             };

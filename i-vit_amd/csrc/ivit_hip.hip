@@ -576,6 +576,10 @@ static int launch_qkv_ws(ivit_handle h, const ivit_linear_plan_s *pl, const int8
         if (e == hipSuccess) e = hipFuncSetAttribute((const void *)gemm_ws_qkv_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_SMEM);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void *)gemm_ws_qkv_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_SMEM);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void *)gemm_ws_qkv_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_SMEM);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)gemm_ws_qkv_kernel<true, true, WS_EPI_RQ8>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_SMEM);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)gemm_ws_qkv_kernel<true, false, WS_EPI_RQ8>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_SMEM);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)gemm_ws_qkv_kernel<false, true, WS_EPI_RQ8>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_SMEM);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)gemm_ws_qkv_kernel<false, false, WS_EPI_RQ8>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_SMEM);
         if (e != hipSuccess) { snprintf(h->err, sizeof(h->err), "qkv attr: %s", hipGetErrorString(e)); return IVIT_ERR_HIP; }
         if (cached) attr_dev[h->device].store(true, std::memory_order_release);
     }
@@ -583,7 +587,16 @@ static int launch_qkv_ws(ivit_handle h, const ivit_linear_plan_s *pl, const int8
     const int ntt = (a.M + 31) / 32;
     const unsigned grid = (unsigned)(ntt < h->num_cu ? ntt : h->num_cu);
     const bool fma = pl->single_fma_ok;
-    if (x16) {
+    if (H == 0) {       // plain 8-bit output [M][N] (q = out8; T = 1)
+        a.T = 1; a.H = 1;
+        if (x16) {
+            if (fma) gemm_ws_qkv_kernel<true, true, WS_EPI_RQ8><<<grid, WS_THREADS, WS_SMEM, h->stream>>>(a);
+            else gemm_ws_qkv_kernel<false, true, WS_EPI_RQ8><<<grid, WS_THREADS, WS_SMEM, h->stream>>>(a);
+        } else {
+            if (fma) gemm_ws_qkv_kernel<true, false, WS_EPI_RQ8><<<grid, WS_THREADS, WS_SMEM, h->stream>>>(a);
+            else gemm_ws_qkv_kernel<false, false, WS_EPI_RQ8><<<grid, WS_THREADS, WS_SMEM, h->stream>>>(a);
+        }
+    } else if (x16) {
         if (fma) gemm_ws_qkv_kernel<true, true><<<grid, WS_THREADS, WS_SMEM, h->stream>>>(a);
         else gemm_ws_qkv_kernel<false, true><<<grid, WS_THREADS, WS_SMEM, h->stream>>>(a);
     } else {
@@ -683,8 +696,21 @@ int ivit_linear_i8_requant_planned(ivit_handle h, ivit_linear_plan pl, const int
     REQUIRE(h, bits == 8 || bits == 16, "bits must be 8 or 16");
     GemmArgs a = linear_args(x, pl->w, pl->bias, M, pl->N, pl->K);
     a.out = out; a.dy_ch = pl->dy;
+    if (IVIT_OPT_QKV_WS && bits == 8 && pl->wf && pl->K == WS_K && M < (1 << 26))      // prepared plan: tokens of a CU in LDS, weight slabs in registers
+        return launch_qkv_ws(h, pl, x, nullptr, 0.f, nullptr, nullptr, nullptr, (int8_t *)out, nullptr, nullptr, M, 1, 0);
     if (use_gemm3(pl, a, 1)) return bits == 8 ? launch_gemm3<EPI_RQ8_CH>(h, pl, a) : launch_gemm3<EPI_RQ16_CH>(h, pl, a);
     return ivit_linear_i8_requant(h, x, pl->w, pl->bias, pl->dy, bits, out, M, pl->N, pl->K);
+}
+
+int ivit_layernorm_linear_i8_requant_planned(ivit_handle h, ivit_linear_plan pl, const int16_t *x16, float scale, const float *bias_int,
+                                             const float *sc, const ivit_dyadic *ln_dy, int8_t *out8, int M) {
+    CHECK_H(h);
+    REQUIRE(h, pl && x16 && bias_int && sc && ln_dy && out8 && M > 0, "bad arguments");
+    if (!(pl->wf && pl->K == WS_K && M < (1 << 26))) {
+        snprintf(h->err, sizeof(h->err), "%s: needs ivit_linear_plan_prepare_ws on a K = 384 plan", __func__);
+        return IVIT_ERR_UNSUPPORTED;
+    }
+    return launch_qkv_ws(h, pl, nullptr, x16, scale, bias_int, sc, ln_dy, out8, nullptr, nullptr, M, 1, 0);
 }
 
 int ivit_linear_i8_requant_residual_planned(ivit_handle h, ivit_linear_plan pl, const int8_t *x, ivit_dyadic dy_main,

@@ -387,6 +387,9 @@ struct ivit_swin_s {
 #ifndef IVIT_OPT_MERGE_LN
 #define IVIT_OPT_MERGE_LN 1            // A/B: PatchMerging's gather folded into its LayerNorm (ivit_patch_merge_layernorm_requant)
 #endif
+#ifndef IVIT_OPT_SWIN_WS
+#define IVIT_OPT_SWIN_WS 1             // A/B: the C = 384 stage's qkv (+ norm1) and proj layers on gemm_ws_qkv_kernel
+#endif
 #ifndef IVIT_OPT_SWIN_PLANS
 #define IVIT_OPT_SWIN_PLANS 0          // A/B: the C = 384 / 768 stages' QuantLinear layers on the planned (persistent) kernels
 #endif
@@ -447,10 +450,17 @@ int swin_run_slice(const ivit_swin_s *m, ivit_handle h, const int8_t *images, in
         for (int bj = 0; bj < c.depths[li]; ++bj, ++bi) {
             const ivit_swin_block &b = m->blocks[bi];
             const int shift = (bj % 2 == 0 || res <= c.window_size) ? 0 : c.window_size / 2;
-            RUN(swin_ln(m, h, x, M, C, b.s_in, b.n1, L, li == 0, a8));
             const ivit_linear_plan *lp = m->lin_plans.empty() ? nullptr : &m->lin_plans[4 * bi];
-            if (lp && lp[0]) RUN(ivit_linear_i8_requant_planned(h, lp[0], a8, 8, qkv, (int)M));
-            else RUN(ivit_linear_i8_requant(h, a8, b.qkv.w, b.qkv.b, b.qkv.dy, 8, qkv, (int)M, 3 * C, C));
+            // norm1 inside the qkv launch where that layer runs on gemm_ws_qkv_kernel (C = 384, activations in natural token order)
+            rc = (IVIT_OPT_SWIN_WS && lp && lp[0] && li != 0) ? ivit_layernorm_linear_i8_requant_planned(h, lp[0], x, b.s_in, b.n1.bias_int, b.n1.sc, b.n1.dy, qkv, (int)M)
+                                                              : IVIT_ERR_UNSUPPORTED;
+            if (rc == IVIT_ERR_UNSUPPORTED) {
+                RUN(swin_ln(m, h, x, M, C, b.s_in, b.n1, L, li == 0, a8));
+                if (lp && lp[0]) RUN(ivit_linear_i8_requant_planned(h, lp[0], a8, 8, qkv, (int)M));
+                else RUN(ivit_linear_i8_requant(h, a8, b.qkv.w, b.qkv.b, b.qkv.dy, 8, qkv, (int)M, 3 * C, C));
+            } else {
+                RUN(rc);
+            }
             if (b.exp_aq)
                 RUN(ivit_window_attention_fused_lut(h, qkv, b.dy_qk, b.dy_a, b.relb, b.s_softmax, b.exp_aq, b.exp_t, b.exp_cls,
                                                     b.exp_nc, b.exp_tcount, b.exp_dmin, b.dy_pv, ctx, B, res, c.window_size,
@@ -576,9 +586,17 @@ int ivit_swin_create(ivit_handle h, const ivit_swin_config *cfg, const ivit_swin
                 m->mlp_lin.push_back(p1);
                 m->mlp_lin.push_back(p2);
                 m->mlp_plans.push_back(mp);
-                if (IVIT_OPT_SWIN_PLANS) {
+                if (IVIT_OPT_SWIN_PLANS || IVIT_OPT_SWIN_WS) {
                     ivit_linear_plan q[4] = {nullptr, nullptr, nullptr, nullptr};
-                    if (C % 384 == 0) {
+                    if (!IVIT_OPT_SWIN_PLANS) {
+                        // round 6: the C = 384 stage's qkv and proj layers on gemm_ws_qkv_kernel (prepared plans), norm1 inside the qkv launch
+                        if (C == WS_K) {
+                            if (ivit_linear_plan_create(h, b.qkv.w, b.qkv.b, b.qkv.dy, 3 * C, C, &q[0]) != IVIT_OK) q[0] = nullptr;
+                            if (q[0] && ivit_linear_plan_prepare_ws(h, q[0]) != IVIT_OK) { (void)ivit_linear_plan_destroy(q[0]); q[0] = nullptr; }
+                            if (ivit_linear_plan_create(h, b.proj.w, b.proj.b, b.proj.dy, C, C, &q[1]) != IVIT_OK) q[1] = nullptr;
+                            if (q[1] && ivit_linear_plan_prepare_ws(h, q[1]) != IVIT_OK) { (void)ivit_linear_plan_destroy(q[1]); q[1] = nullptr; }
+                        }
+                    } else if (C % 384 == 0) {
                         if (ivit_linear_plan_create(h, b.qkv.w, b.qkv.b, b.qkv.dy, 3 * C, C, &q[0]) != IVIT_OK) q[0] = nullptr;
                         if (ivit_linear_plan_create(h, b.proj.w, b.proj.b, b.proj.dy, C, C, &q[1]) != IVIT_OK) q[1] = nullptr;
                         if (!mp) {

@@ -49,7 +49,7 @@ enum {
 };
 
 /* 100 * major + minor.  103 (round 6): ivit_linear_plan_prepare_ws, ivit_layernorm_linear_i8_qkv_planned,
- * ivit_linear_i8_requant_residual_layernorm_planned (additions only).
+ * ivit_linear_i8_requant_residual_layernorm_planned, ivit_layernorm_linear_i8_requant_planned (additions only).
  * 102 (round 6): ivit_shiftmax_rowtable, ivit_attention_fused_rowlut (additions only).
  * 101 (round 5): ivit_mlp_plan_select; ivit_swin_block / ivit_vit_block carry the optional Shiftmax-table
  * fields exp_* at their END (added in 100 without a bump: a caller compiled against an older layout must be rebuilt).
@@ -153,6 +153,12 @@ int ivit_linear_i8_qkv_planned(ivit_handle h, ivit_linear_plan p, const int8_t *
  * norm1's 8-bit output never exists in HBM.  IVIT_ERR_UNSUPPORTED (nothing launched) unless the plan is prepared, dh = 64 and
  * B*H*T*64 < 2^31.                                                                                             */
 int ivit_linear_plan_prepare_ws(ivit_handle h, ivit_linear_plan p);
+/* IntLayerNorm + QuantAct(8) + QuantLinear + QuantAct(8) in one launch, plain [M, N] output (swin_quant.py:256-258 + 121-130: norm1 -> qact1 -> attn.qkv of a
+ * C = 384 block, activations in natural token order): out8 == ivit_layernorm_requant followed by ivit_linear_i8_requant_planned(bits = 8).
+ * IVIT_ERR_UNSUPPORTED (nothing launched) unless the plan is a prepared K = 384 one.  On a prepared plan
+ * ivit_linear_i8_requant_planned(bits = 8) runs on the same kernel.                                                            */
+int ivit_layernorm_linear_i8_requant_planned(ivit_handle h, ivit_linear_plan p, const int16_t *x16, float scale,
+                                             const float *bias_int, const float *sc, const ivit_dyadic *ln_dy, int8_t *out8, int M);
 /* attn.proj + qact2 with the identity branch + norm2 + qact3 of a D = 384 block in ONE launch (vit_quant.py:137-140):
  * out [M, 384] = ivit_linear_i8_requant_residual_planned's result, ln_out8 [M, 384] = ivit_layernorm_requant(out, ln_scale,
  * ln_bias_int, ln_sc, ln_dy) — the workgroup that produced a row normalises it.  IVIT_ERR_UNSUPPORTED (nothing launched) unless

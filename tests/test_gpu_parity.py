@@ -1229,6 +1229,45 @@ def test_layernorm_qkv_fused_vs_oracle(H, B, T):
     plain.close(); prepared.close()
 
 
+@pytest.mark.parametrize("M,N", [(1, 1152), (196, 1152), (6000, 1152), (50176, 1152), (3000, 64), (3000, 1536)])
+def test_layernorm_linear_plain_fused_vs_oracle(H, M, N):
+    """IntLayerNorm -> QuantAct(8) -> QuantLinear -> QuantAct(8) with a plain [M, N] output in one launch
+    (ivit_layernorm_linear_i8_requant_planned: norm1 + attn.qkv of a Swin C = 384 block, swin_quant.py:256-258) and
+    ivit_linear_i8_requant_planned(bits = 8) on a prepared plan: == the oracle for the small shapes, == the two launches on an
+    unprepared plan for all; guard rows."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(M * 3 + N)
+    D = 384
+    wln = rng.normal(1.0, 0.4, D).astype(np.float32) * rng.choice([-1.0, 1.0], D).astype(np.float32)
+    bias_int, sc = iv.freeze.layernorm_constants(wln, rng.normal(0.0, 0.5, D).astype(np.float32))
+    s_in, s_out = np.float32(7.3e-4), np.float32(0.031)
+    x16 = rng.integers(-26000, 26000, (M, D)).astype(np.int16)
+    x16[:, : D // 2] //= 64
+    w = np.rint(rng.normal(0, 45, (N, D)).clip(-128, 127)).astype(np.int8)
+    b = rng.integers(-2 ** 14, 2 ** 14, N).astype(np.int32)
+    s_pre, s_q = (10 ** rng.uniform(-5.5, -5, N)).astype(np.float32), np.float32(0.02)
+    xd, bi_d, sc_d, dln = dev(x16), dev(bias_int), dev(sc), dev(iv.freeze.dyadic(sc, s_out))
+    wd, bd, d = dev(w), dev(b), dev(iv.freeze.dyadic(s_pre, s_q))
+    plain, prepared = H.linear_plan(P(wd), P(bd), P(d), N, D), H.linear_plan(P(wd), P(bd), P(d), N, D)
+    H.call("ivit_linear_plan_prepare_ws", prepared.p)
+    a8 = torch.empty(M, D, dtype=torch.int8, device="cuda")
+    H.call("ivit_layernorm_requant", P(xd), M, D, D, float(s_in), P(bi_d), P(sc_d), P(dln), P(a8))
+    mk = lambda: torch.full((M + 1, N), 77, dtype=torch.int8, device="cuda")
+    ref, alone, fused = mk(), mk(), mk()
+    H.call("ivit_linear_i8_requant_planned", plain.p, P(a8), 8, P(ref), M)
+    H.call("ivit_linear_i8_requant_planned", prepared.p, P(a8), 8, P(alone), M)
+    H.call("ivit_layernorm_linear_i8_requant_planned", prepared.p, P(xd), float(s_in), P(bi_d), P(sc_d), P(dln), P(fused), M)
+    assert torch.equal(alone, ref) and torch.equal(fused, ref), (int((alone != ref).sum()), int((fused != ref).sum()))
+    assert (ref[-1] == 77).all()
+    if M * N <= 8_000_000:
+        ln8 = orc.requant(orc.layernorm(x16, float(s_in), bias_int, sc), orc.dyadic(sc, s_out), 8)
+        want = orc.requant(orc.linear_i8(ln8.astype(np.int8), w, b), orc.dyadic(s_pre, s_q), 8)
+        assert np.array_equal(ref[:-1].cpu().numpy().astype(np.int32), want) and len(np.unique(want)) > 50
+    with pytest.raises(_lib.IvitError, match="prepare_ws"):
+        H.call("ivit_layernorm_linear_i8_requant_planned", plain.p, P(xd), float(s_in), P(bi_d), P(sc_d), P(dln), P(fused), M)
+    plain.close(); prepared.close()
+
+
 @pytest.mark.parametrize("M,N", [(1, 384), (197, 384), (591, 384), (7000, 384), (50432, 384), (60000, 384), (1000, 128), (1000, 1536)])
 def test_residual_linear_on_prepared_plan_vs_oracle(H, M, N):
     """attn.proj + qact2 with the identity branch (vit_quant.py:137-138, quant_utils.py:238-244) of a K = 384 layer on
