@@ -1,3 +1,8 @@
+// EXPERIMENT RECORD (round 6) — the scaffold the shipped i-vit_amd/csrc/ivit_gemm_ws.h grew out of, in its last experimental state: next task's
+// weights requested behind the last K loop of the current one (WS "v3", 38.7 us against 35.5 for reloading at task start), half-a-first DMA with a
+// second barrier, a per-SIMD MFMA baton (WS_BATON), s_setprio variants (WS_PRIO), B fragments two k-steps ahead (WS_PF), a hand-staged epilogue
+// (WS_PIN = 64), fine cycle stamps (WS_TRACE / WS_FINE).  None of these is in the product; profiles/README.md (round 6, top) has the numbers.
+// Compiles stand-alone (template gemm_ws_qkv_kernel<FMA>), qkv flavour only.
 // ivit_gemm_ws.h — K = 384 QuantLinear (models/quantization_utils/quant_modules.py:21-80, the qkv flavour of
 // models/vit_quant.py:65-74) with the WEIGHTS of a 32-channel tile resident in registers and the tokens of a whole CU in LDS:
 //
