@@ -390,7 +390,7 @@ def main():
     # few untimed steps and the faster one is the mode of the warm-up and of the timed region; the choice is reported.
     mode_trials = None
     pinned = any(a.split("=")[0] in ("--streams", "--graph") for a in sys.argv[1:]) or "IVIT_STREAMS" in os.environ or "IVIT_GRAPH" in os.environ
-    if args.auto_mode and not pinned and batch > 1:
+    if args.auto_mode and not pinned:        # (batch 1 too: DeiT-T b1 is 0.69 ms eager against 0.83 as a graph replay)
         mode_trials = []
         for ns, gr in ((streams, 1), (1, 0)):
             st = make_step(ns, gr)
