@@ -221,6 +221,7 @@ SIGNATURES = {
     "ivit_debug_requotient": [_P, _P, _P, _P, _P, _L],
     "ivit_im2col_patch": [_P, _P, _I, _I, _I, _I, _I, _P],
     "ivit_embed_finish": [_P, _P, _P, _P, Dyadic, Dyadic, _P, _I, _I, _I],
+    "ivit_patch_embed": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, Dyadic, Dyadic, _P, _I],
 }
 OTHER_SYMBOLS = ["ivit_version", "ivit_status_string", "ivit_last_error", "ivit_linear_plan_destroy", "ivit_mlp_plan_destroy", "ivit_linear_plan_query", "ivit_debug_plan_scratch", "ivit_mlp_plan_select"]
 

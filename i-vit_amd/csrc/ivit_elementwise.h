@@ -573,13 +573,14 @@ __global__ __launch_bounds__(256) void embed_finish_kernel(const int16_t *__rest
                                                            const int32_t *__restrict__ z_cls,
                                                            const int16_t *__restrict__ pos, ivit_dyadic dx,
                                                            ivit_dyadic dp, int16_t *__restrict__ x16, int T,
-                                                           int D, float inv_d8, int fast) {
+                                                           int D, float inv_d8, int fast, int only_cls = 0) {
     // one thread per 8 channels (16-byte loads/stores), one image per blockIdx.y; (token, channel group) from the flat index
     // by a float reciprocal (exact: T * D / 8 < 2^22), no integer division
     const int D8 = D >> 3, b = blockIdx.y;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= T * D8) return;
     const int t = (int)(((float)idx + 0.5f) * inv_d8), c8 = idx - t * D8;
+    if (only_cls && t != 0) return;        // the patch rows come out of the patch-embedding GEMM's epilogue (ivit_patch_embed)
     const double cx = dx.m * dx.r, cp = dp.m * dp.r;
     const v8s pv = *reinterpret_cast<const v8s *>(pos + (long long)t * D + c8 * 8);
     v8s o;

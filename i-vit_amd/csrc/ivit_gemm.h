@@ -44,6 +44,11 @@ struct GemmArgs {
     int T, H, dh, ldv, D;
     int tiles_n;
     int dbg;   // debug/ablation switch (env IVIT_GEMM_DBG), 0 in production
+    // patch embedding in one launch (gemm_glds_kernel<EPI_RQ16_CH_RES, BM, IM2COL = true>, ivit_patch_embed): A rows are gathered from the
+    // images (16 x 16 patches: every 16-byte chunk of an im2col row is one pixel row of the patch), row r of the GEMM is patch r % pe_P of image
+    // r / pe_P, its residual row is pos[r % pe_P + 1] and its output row r + r / pe_P + 1 (the class-token rows are written by embed_finish_kernel)
+    const int8_t *img;
+    int img_C, img_H, img_W, pe_gw, pe_P;
 };
 
 #define GEMM_BM 128

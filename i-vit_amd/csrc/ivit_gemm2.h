@@ -48,17 +48,19 @@ __device__ __forceinline__ int rq_lean_wide(int z, double c) { return rint_sat_i
 
 // kchunks: valid 16-byte chunks of this K step (4, or 2 for the 32-wide tail step when K % 64 == 32): lanes whose
 // chunk lies beyond K are masked off — their LDS slots keep stale bytes that the tail step never feeds to an MFMA
-template <int BM>
-__device__ __forceinline__ void g2_issue(const int8_t *A, const int8_t *B, int lda, int ldb, int M, int N,
-                                         int row0, int col0, int k0, char *stage, int tid, int kchunks = 4) {
+// abase[i]: this thread's two A rows (row i * THREADS / 4 + tid / 4 of the tile) — the row's first byte, or (IM2COL) the top-left pixel of
+// its patch in channel 0; hw = H * W, w = W of the images
+template <int BM, bool IM2COL = false>
+__device__ __forceinline__ void g2_issue(const int8_t *const (&abase)[2], const int8_t *B, int ldb, int N, int col0, int k0, char *stage,
+                                         int tid, int kchunks = 4, long long hw = 0, int w = 0) {
     using Cf = G2Cfg<BM>;
     const int wave = tid >> 6;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         int id = tid + i * Cf::THREADS, row = id >> 2, pos = id & 3;
         int c = pos ^ ((row >> 2) & 3);
-        int grow = min(row0 + row, M - 1);
-        const int8_t *src = A + (long long)grow * lda + k0 + c * 16;
+        const int q = (k0 >> 4) + c;                    // IM2COL: chunk q of the row = channel q / 16, pixel row q % 16 of the patch
+        const int8_t *src = IM2COL ? abase[i] + (long long)(q >> 4) * hw + (q & 15) * w : abase[i] + k0 + c * 16;
         unsigned loff = __builtin_amdgcn_readfirstlane((unsigned)(i * (Cf::THREADS * 16) + wave * 1024));
         if (c < kchunks)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
@@ -77,7 +79,7 @@ __device__ __forceinline__ void g2_issue(const int8_t *A, const int8_t *B, int l
     }
 }
 
-template <int EPI, int BM>
+template <int EPI, int BM, bool IM2COL = false>
 __global__ __launch_bounds__(BM * 2, BM == 256 ? 4 : (G2_NSTAGE128 == 2 ? 4 : 3)) void gemm_glds_kernel(GemmArgs p) {
     using Cf = G2Cfg<BM>;
     constexpr int G2_BM = BM, G2_STAGE = Cf::STAGE, G2_SMEM = Cf::SMEM, NT = Cf::THREADS;
@@ -102,8 +104,20 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 4 : (G2_NSTAGE128 == 2 ? 4 : 3)
     const int nk = (Kdim + G2_BK - 1) / G2_BK;
     const bool ktail = (Kdim % G2_BK) != 0;            // K % 64 == 32: the last step carries 32 columns
     auto kch = [&](int kt) { return (ktail && kt == nk - 1) ? 2 : 4; };
-    g2_issue<BM>(A, B, p.lda, p.ldb, p.M, p.N, row0, col0, 0, smem, tid, kch(0));
-    if (NS == 3 && nk > 1) g2_issue<BM>(A, B, p.lda, p.ldb, p.M, p.N, row0, col0, G2_BK, smem + G2_STAGE, tid, kch(1));
+    const int8_t *abase[2];
+    const long long img_hw = IM2COL ? (long long)p.img_H * p.img_W : 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int grow = min(row0 + ((tid + i * NT) >> 2), p.M - 1);
+        if (IM2COL) {
+            const int b = grow / p.pe_P, rem = grow - b * p.pe_P, gy = rem / p.pe_gw, gx = rem - gy * p.pe_gw;
+            abase[i] = p.img + ((long long)b * p.img_C * p.img_H + gy * 16) * p.img_W + gx * 16;
+        } else {
+            abase[i] = A + (long long)grow * p.lda;
+        }
+    }
+    g2_issue<BM, IM2COL>(abase, B, p.ldb, p.N, col0, 0, smem, tid, kch(0), img_hw, p.img_W);
+    if (NS == 3 && nk > 1) g2_issue<BM, IM2COL>(abase, B, p.ldb, p.N, col0, G2_BK, smem + G2_STAGE, tid, kch(1), img_hw, p.img_W);
 
     // per-channel constants of this column block -> LDS (read back in the epilogue; the
     // K-loop barriers order the write): c[n] = m*2^-e (exact in fp64), bias[n]
@@ -145,8 +159,8 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 4 : (G2_NSTAGE128 == 2 ? 4 : 3)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (kt + NS - 1 < nk)
-            g2_issue<BM>(A, B, p.lda, p.ldb, p.M, p.N, row0, col0, (kt + NS - 1) * G2_BK,
-                     smem + ((kt + NS - 1) % NS) * G2_STAGE, tid, kch(kt + NS - 1));
+            g2_issue<BM, IM2COL>(abase, B, p.ldb, p.N, col0, (kt + NS - 1) * G2_BK,
+                                 smem + ((kt + NS - 1) % NS) * G2_STAGE, tid, kch(kt + NS - 1), img_hw, p.img_W);
         const char *sA = smem + (kt % NS) * G2_STAGE;
         const char *sB = sA + BM * 64;
 #pragma unroll
@@ -255,10 +269,12 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 4 : (G2_NSTAGE128 == 2 ? 4 : 3)
                 const char *sp = smem + row * G2_LD16 + c * 16;
                 v2i lo = *reinterpret_cast<const v2i *>(sp), hi = *reinterpret_cast<const v2i *>(sp + 8);
                 v4i v = {lo[0], lo[1], hi[0], hi[1]};
-                int16_t *dst = out + (long long)grow * p.ldc + gcol;
+                // (patch embedding: output row behind its image's class-token row, residual = the patch's position embedding)
+                const int pimg = IM2COL ? grow / p.pe_P : 0;
+                int16_t *dst = out + (long long)(IM2COL ? grow + pimg + 1 : grow) * p.ldc + gcol;
                 const bool vec = (gcol + 8 <= p.N) && ((p.ldc & 7) == 0);
                 if (EPI == EPI_RQ16_CH_RES) {
-                    const int16_t *rp = p.residual + (long long)grow * p.ldc + gcol;
+                    const int16_t *rp = p.residual + (long long)(IM2COL ? grow - pimg * p.pe_P + 1 : grow) * p.ldc + gcol;
                     v4i rs = {0, 0, 0, 0};
                     if (vec) {
                         rs = *reinterpret_cast<const v4i *>(rp);

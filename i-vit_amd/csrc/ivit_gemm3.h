@@ -217,7 +217,11 @@ __global__ __launch_bounds__(G3Cfg<ASTAT>::NT, 2) void gemm_ps_kernel(GemmArgs p
             }
             if (!skip) g3_issue_w128(B, p.ldb, p.N, col0, l_kt * G2_BK, ring + l_slot * Cf::STAGE, tid);
         } else {
-            if (!skip) g2_issue<128>(A, B, p.lda, p.ldb, p.M, p.N, row0, col0, l_kt * G2_BK, ring + l_slot * Cf::STAGE, tid);
+            if (!skip) {
+                const int8_t *abase[2] = {A + (long long)min(row0 + (tid >> 2), p.M - 1) * p.lda,
+                                          A + (long long)min(row0 + ((tid + G2Cfg<128>::THREADS) >> 2), p.M - 1) * p.lda};
+                g2_issue<128>(abase, B, p.ldb, p.N, col0, l_kt * G2_BK, ring + l_slot * Cf::STAGE, tid);
+            }
             infl = 4;
         }
         if (skip) infl = 0;

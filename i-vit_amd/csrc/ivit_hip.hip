@@ -1408,6 +1408,36 @@ int ivit_embed_finish(ivit_handle h, const int16_t *patch16, const int32_t *z_cl
     return IVIT_OK;
 }
 
+#ifndef IVIT_OPT_PATCH_EMBED
+#define IVIT_OPT_PATCH_EMBED 1          // A/B: 0 = ivit_patch_embed always answers IVIT_ERR_UNSUPPORTED (im2col + GEMM + embed_finish launches)
+#endif
+int ivit_patch_embed(ivit_handle h, const int8_t *images, int B, int C, int H, int W, int P, const int8_t *w, const int32_t *bias,
+                     const ivit_dyadic *dy_ch, const int32_t *z_cls, const int16_t *pos, ivit_dyadic dy_x, ivit_dyadic dy_pos,
+                     int16_t *x16, int D) {
+    CHECK_H(h);
+    REQUIRE(h, images && w && dy_ch && z_cls && pos && x16 && B > 0 && C > 0 && H > 0 && W > 0 && P > 0 && D > 0, "bad arguments");
+    const int gh = H / P, gw = W / P, np = gh * gw, K = C * P * P, T = np + 1;
+    const bool fast = fabs(dy_x.m * dy_x.r) < RQ_FAST_CLIM && fabs(dy_pos.m * dy_pos.r) < RQ_FAST_CLIM;
+    GemmArgs a = linear_args(images, w, bias, B * np, D, K);
+    if (!IVIT_OPT_PATCH_EMBED || P != 16 || H % 16 || W % 16 || (D % 8) != 0 || (K % 64) != 0 || !fast || !use_gemm2(a) || (long long)B * np >= (1ll << 30) ||
+        (long long)T * D / 8 >= (1 << 22) || B > 65535) {
+        snprintf(h->err, sizeof(h->err), "%s: built for 16 x 16 patches, K %% 64 == 0, both multipliers in the fast range", __func__);
+        return IVIT_ERR_UNSUPPORTED;
+    }
+    // class-token rows, then every patch row from the GEMM's epilogue: QuantConv2d -> QuantAct(16) -> + pos -> QuantAct(16) (vit_quant.py:255-265)
+    embed_finish_kernel<<<dim3((unsigned)((D / 8 + 255) / 256), (unsigned)B), 256, 0, h->stream>>>(nullptr, z_cls, pos, dy_x, dy_pos, x16, T, D,
+                                                                                                  1.0f / (float)(D / 8), 1, 1);
+    LAUNCH_CHECK(h);
+    a.out = x16; a.dy_ch = dy_ch; a.dy_main = dy_x; a.dy_res = dy_pos; a.residual = pos;
+    a.img = images; a.img_C = C; a.img_H = H; a.img_W = W; a.pe_gw = gw; a.pe_P = np;
+    a.tiles_n = (a.N + G2_BN - 1) / G2_BN;
+    a.dbg = 0;
+    const long long t128 = (long long)((a.M + 127) / 128) * a.tiles_n;
+    gemm_glds_kernel<EPI_RQ16_CH_RES, 128, true><<<dim3((unsigned)t128), 256, 0, h->stream>>>(a);
+    LAUNCH_CHECK(h);
+    return IVIT_OK;
+}
+
 }  // extern "C"
 
 extern "C" {

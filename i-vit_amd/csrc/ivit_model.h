@@ -101,9 +101,18 @@ int run_slice(const ivit_vit_s *m, ivit_handle h, const int8_t *images, int B, i
     int16_t *patch16 = (int16_t *)(ws + L.patch16), *x = (int16_t *)(ws + L.xa), *y = (int16_t *)(ws + L.xb);
     int rc;
 #define RUN(call) do { rc = (call); if (rc != IVIT_OK) { if (h != m->h) snprintf(m->h->err, sizeof(m->h->err), "%s", h->err); return rc; } } while (0)
-    RUN(ivit_im2col_patch(h, images, B, c.in_chans, c.img_size, c.img_size, c.patch_size, patches));
-    RUN(ivit_linear_i8_requant(h, patches, P.pe_w, P.pe_b, P.pe_dy, 16, patch16, B * m->num_patches, D, m->Kp));
-    RUN(ivit_embed_finish(h, patch16, P.z_cls, P.pos, P.dy_x, P.dy_pos, x, B, T, D));
+    // PatchEmbed + class token + position embedding: one GEMM launch that gathers its A rows from the images and finishes the rows in its
+    // epilogue (round 6), or im2col -> GEMM -> embed_finish where that form does not apply
+    rc = (m->Kp == c.in_chans * c.patch_size * c.patch_size)
+             ? ivit_patch_embed(h, images, B, c.in_chans, c.img_size, c.img_size, c.patch_size, P.pe_w, P.pe_b, P.pe_dy, P.z_cls, P.pos, P.dy_x, P.dy_pos, x, D)
+             : IVIT_ERR_UNSUPPORTED;
+    if (rc == IVIT_ERR_UNSUPPORTED) {
+        RUN(ivit_im2col_patch(h, images, B, c.in_chans, c.img_size, c.img_size, c.patch_size, patches));
+        RUN(ivit_linear_i8_requant(h, patches, P.pe_w, P.pe_b, P.pe_dy, 16, patch16, B * m->num_patches, D, m->Kp));
+        RUN(ivit_embed_finish(h, patch16, P.z_cls, P.pos, P.dy_x, P.dy_pos, x, B, T, D));
+    } else {
+        RUN(rc);
+    }
     for (int i = 0; i < c.depth; ++i) {
         const ivit_vit_block &b = m->blocks[i];
         // a layer on the row-table attention takes v ROW-major (ldv = 0: the qkv GEMM stores 16 bytes per lane instead of 16 byte

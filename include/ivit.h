@@ -49,7 +49,7 @@ enum {
 };
 
 /* 100 * major + minor.  103 (round 6): ivit_linear_plan_prepare_ws, ivit_layernorm_linear_i8_qkv_planned,
- * ivit_linear_i8_requant_residual_layernorm_planned, ivit_layernorm_linear_i8_requant_planned (additions only).
+ * ivit_linear_i8_requant_residual_layernorm_planned, ivit_layernorm_linear_i8_requant_planned, ivit_patch_embed (additions only).
  * 102 (round 6): ivit_shiftmax_rowtable, ivit_attention_fused_rowlut (additions only).
  * 101 (round 5): ivit_mlp_plan_select; ivit_swin_block / ivit_vit_block carry the optional Shiftmax-table
  * fields exp_* at their END (added in 100 without a bump: a caller compiled against an older layout must be rebuilt).
@@ -290,6 +290,14 @@ int ivit_im2col_patch(ivit_handle h, const int8_t *img, int B, int Cin, int H, i
 int ivit_embed_finish(ivit_handle h, const int16_t *patch16, const int32_t *z_cls,
                       const int16_t *pos, ivit_dyadic dy_x, ivit_dyadic dy_pos, int16_t *x16,
                       int B, int T, int D);
+/* Round 6: the three steps above in one GEMM launch (plus the B class-token rows): the A rows are gathered from the NCHW images
+ * (every 16-byte chunk of an im2col row is one pixel row of a 16 x 16 patch), the epilogue requantises to 16 bits, adds the
+ * patch's position embedding and writes row 1 + i of its image.  w [D, Cin*P*P] in conv-weight order, bias int32 [D] or NULL,
+ * dy_ch [D] as for ivit_linear_i8_requant(bits = 16).  x16 == ivit_im2col_patch -> ivit_linear_i8_requant(16) -> ivit_embed_finish.
+ * IVIT_ERR_UNSUPPORTED (nothing launched) unless P == 16, H and W multiples of 16, Cin*P*P a multiple of 64 and |dy_x|, |dy_pos| < 2^9. */
+int ivit_patch_embed(ivit_handle h, const int8_t *images, int B, int Cin, int H, int W, int P, const int8_t *w,
+                     const int32_t *bias, const ivit_dyadic *dy_ch, const int32_t *z_cls, const int16_t *pos,
+                     ivit_dyadic dy_x, ivit_dyadic dy_pos, int16_t *x16, int D);
 
 /* ---- a9-a11  whole-model runner: VisionTransformer.forward (vit_quant.py:254-282) with
  * Block.forward (:130-143), Attention.forward (:59-88) and Mlp.forward (layers_quant.py:144-153)

@@ -1229,6 +1229,38 @@ def test_layernorm_qkv_fused_vs_oracle(H, B, T):
     plain.close(); prepared.close()
 
 
+@pytest.mark.parametrize("B,C,HW,D", [(1, 3, 224, 384), (5, 3, 224, 384), (3, 3, 64, 192), (2, 1, 96, 768), (70, 3, 224, 384)])
+def test_patch_embed_one_launch_equals_three(H, B, C, HW, D):
+    """PatchEmbed -> QuantAct(16) -> class token + position embedding -> QuantAct(16) (layers_quant.py:184-196, vit_quant.py:255-265) as ONE
+    GEMM launch that gathers its rows from the images (ivit_patch_embed) == ivit_im2col_patch + ivit_linear_i8_requant(16) +
+    ivit_embed_finish (each pinned against the oracle elsewhere), bit for bit, guard row behind the output; the form is refused for
+    8 x 8 patches and for multipliers outside the fast range."""
+    rng = np.random.default_rng(B * 131 + HW + D)
+    P16, g = 16, HW // 16
+    np_, K, T = g * g, C * 256, g * g + 1
+    img = dev(rng.integers(-128, 128, (B, C, HW, HW), dtype=np.int8))
+    w = dev(np.rint(rng.normal(0, 40, (D, K)).clip(-128, 127)).astype(np.int8))
+    b = dev(rng.integers(-2 ** 14, 2 ** 14, D).astype(np.int32))
+    d = dev(iv.freeze.dyadic((10 ** rng.uniform(-5.5, -5, D)).astype(np.float32), np.float32(2e-4)))
+    z_cls = dev(rng.integers(-10 ** 6, 10 ** 6, D).astype(np.int32))
+    pos = dev(rng.integers(-20000, 20000, (T, D)).astype(np.int16))
+    dx, dp = iv.freeze.dyadic(np.float32(2e-4), np.float32(7e-4)), iv.freeze.dyadic(np.float32(5e-4), np.float32(7e-4))
+    rows = torch.empty(B * np_, K, dtype=torch.int8, device="cuda")
+    p16 = torch.empty(B * np_, D, dtype=torch.int16, device="cuda")
+    want = torch.full((B * T + 1, D), 77, dtype=torch.int16, device="cuda")
+    got = torch.full((B * T + 1, D), 77, dtype=torch.int16, device="cuda")
+    H.call("ivit_im2col_patch", P(img), B, C, HW, HW, P16, P(rows))
+    H.call("ivit_linear_i8_requant", P(rows), P(w), P(b), P(d), 16, P(p16), B * np_, D, K)
+    H.call("ivit_embed_finish", P(p16), P(z_cls), P(pos), dyv(dx), dyv(dp), P(want), B, T, D)
+    H.call("ivit_patch_embed", P(img), B, C, HW, HW, P16, P(w), P(b), P(d), P(z_cls), P(pos), dyv(dx), dyv(dp), P(got), D)
+    assert torch.equal(got, want), int((got != want).sum())
+    assert (got[-1] == 77).all() and len(torch.unique(want)) > 1000
+    with pytest.raises(_lib.IvitError, match="16 x 16"):
+        H.call("ivit_patch_embed", P(img), B, C, HW, HW, 8, P(w), P(b), P(d), P(z_cls), P(pos), dyv(dx), dyv(dp), P(got), D)
+    with pytest.raises(_lib.IvitError, match="16 x 16"):
+        H.call("ivit_patch_embed", P(img), B, C, HW, HW, P16, P(w), P(b), P(d), P(z_cls), P(pos), _lib.Dyadic(1024.0, 1.0), dyv(dp), P(got), D)
+
+
 @pytest.mark.parametrize("M,N", [(1, 1152), (196, 1152), (6000, 1152), (50176, 1152), (3000, 64), (3000, 1536)])
 def test_layernorm_linear_plain_fused_vs_oracle(H, M, N):
     """IntLayerNorm -> QuantAct(8) -> QuantLinear -> QuantAct(8) with a plain [M, N] output in one launch
