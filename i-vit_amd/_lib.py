@@ -165,6 +165,7 @@ SIGNATURES = {
     "ivit_window_attention_fused_lut": [_P, _P, Dyadic, Dyadic, _P, _F, _P, _P, _P, _I, _I, _I, Dyadic, _P, _I, _I, _I, _I, _I, _I],
     "ivit_mlp_plan_create": [_P, _P, _P, ctypes.POINTER(_P)],
     "ivit_mlp_fused_planned": [_P, _P, _P, _P, Dyadic, Dyadic, _P, _P, _L],
+    "ivit_layernorm_mlp_fused_planned": [_P, _P, _P, _F, _P, _P, _P, _P, _P, Dyadic, Dyadic, _P, _L],
     "ivit_mlp_fused": [_P, _P, _P, _P, _P, _P, _P, _P, _P, Dyadic, Dyadic, _P, _P, _L, _I, _I],
     "ivit_patch_merge_gather": [_P, _P, _I, _I, _I, _I, _P],
     "ivit_widen_i8_i16": [_P, _P, _P, _L],

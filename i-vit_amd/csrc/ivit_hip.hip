@@ -842,8 +842,10 @@ int ivit_mlp_plan_create(ivit_handle h, ivit_linear_plan fc1, ivit_linear_plan f
     {   // the dynamic-LDS attributes of the kernels this plan will launch: once, here
         const void *fn = p->fma ? (const void *)mlp384_kernel<true> : (const void *)mlp384_kernel<false>;
         const void *fr = p->fma ? (const void *)mlp384rs_kernel<true> : (const void *)mlp384rs_kernel<false>;
+        const void *fl = p->fma ? (const void *)mlp384rs_kernel<true, true> : (const void *)mlp384rs_kernel<false, true>;
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_SMEM);
         if (e == hipSuccess) e = hipFuncSetAttribute(fr, hipFuncAttributeMaxDynamicSharedMemorySize, RS_SMEM);
+        if (e == hipSuccess) e = hipFuncSetAttribute(fl, hipFuncAttributeMaxDynamicSharedMemorySize, RS_SMEM);
         if (e != hipSuccess) {
             snprintf(h->err, sizeof(h->err), "%s: attr: %s", __func__, hipGetErrorString(e));
             (void)hipFree(dev);
@@ -870,11 +872,11 @@ int ivit_mlp_plan_destroy(ivit_mlp_plan p) {
     return IVIT_OK;
 }
 
-int ivit_mlp_fused_planned(ivit_handle h, ivit_mlp_plan p, const int8_t *x, const int8_t *gelu_table, ivit_dyadic dy_main,
-                           ivit_dyadic dy_res, const int16_t *residual, int16_t *out, int64_t M) {
-    CHECK_H(h);
-    REQUIRE(h, p && x && gelu_table && residual && out && M > 0, "bad arguments");
+static int mlp_fused_launch(ivit_handle h, ivit_mlp_plan p, const int8_t *x, const int8_t *gelu_table, ivit_dyadic dy_main,
+                            ivit_dyadic dy_res, const int16_t *residual, int16_t *out, int64_t M, float ln_s, const float *ln_bias_int,
+                            const float *ln_sc, const ivit_dyadic *ln_dy) {
     MlpArgs a;
+    a.ln_s = ln_s; a.ln_bias_int = ln_bias_int; a.ln_sc = ln_sc; a.ln_dy = ln_dy;
     a.x = x; a.w1f = p->w1f; a.w2f = p->w2f; a.b1 = p->fc1->bias_eff; a.b2 = p->fc2->bias_eff;
     a.cq1 = p->fc1->cq; a.cq2 = p->fc2->cq; a.tab = gelu_table; a.residual = residual; a.out = out;
     a.cm = dy_main.m * dy_main.r; a.cr = dy_res.m * dy_res.r; a.M = M; a.trace = nullptr;
@@ -893,14 +895,36 @@ int ivit_mlp_fused_planned(ivit_handle h, ivit_mlp_plan p, const int8_t *x, cons
     // ShiftGELU / fc2 / epilogue of unit u) needs a second unit per workgroup to overlap anything: with one unit per CU it only
     // ties with the lock-step kernel (45.0 vs 44.6 us at M = 20480), from two units on it wins (profiles/README.md, round 5)
     const bool role_split = p->kernel == 2 || (p->kernel == 0 && IVIT_OPT_MLP_RS && nunits > (long long)grid);
+    if (ln_dy && !role_split) {
+        snprintf(h->err, sizeof(h->err), "%s: the LayerNorm prologue exists in the role-split kernel only (two units per CU or more)", __func__);
+        return IVIT_ERR_UNSUPPORTED;
+    }
     if (role_split) {
         a.w1f = p->w1r; a.w2f = p->w2r;
-        if (p->fma) mlp384rs_kernel<true><<<grid, RS_THREADS, RS_SMEM, h->stream>>>(a);
+        if (ln_dy) {
+            if (p->fma) mlp384rs_kernel<true, true><<<grid, RS_THREADS, RS_SMEM, h->stream>>>(a);
+            else mlp384rs_kernel<false, true><<<grid, RS_THREADS, RS_SMEM, h->stream>>>(a);
+        } else if (p->fma) mlp384rs_kernel<true><<<grid, RS_THREADS, RS_SMEM, h->stream>>>(a);
         else mlp384rs_kernel<false><<<grid, RS_THREADS, RS_SMEM, h->stream>>>(a);
     } else if (p->fma) mlp384_kernel<true><<<grid, MLP_THREADS, MLP_SMEM, h->stream>>>(a);
     else mlp384_kernel<false><<<grid, MLP_THREADS, MLP_SMEM, h->stream>>>(a);
     LAUNCH_CHECK(h);
     return IVIT_OK;
+}
+
+int ivit_mlp_fused_planned(ivit_handle h, ivit_mlp_plan p, const int8_t *x, const int8_t *gelu_table, ivit_dyadic dy_main,
+                           ivit_dyadic dy_res, const int16_t *residual, int16_t *out, int64_t M) {
+    CHECK_H(h);
+    REQUIRE(h, p && x && gelu_table && residual && out && M > 0, "bad arguments");
+    return mlp_fused_launch(h, p, x, gelu_table, dy_main, dy_res, residual, out, M, 0.f, nullptr, nullptr, nullptr);
+}
+
+int ivit_layernorm_mlp_fused_planned(ivit_handle h, ivit_mlp_plan p, const int16_t *x16, float scale, const float *bias_int, const float *sc,
+                                     const ivit_dyadic *ln_dy, int8_t *scratch8, const int8_t *gelu_table, ivit_dyadic dy_main,
+                                     ivit_dyadic dy_res, int16_t *out, int64_t M) {
+    CHECK_H(h);
+    REQUIRE(h, p && x16 && bias_int && sc && ln_dy && scratch8 && gelu_table && out && M > 0, "bad arguments");
+    return mlp_fused_launch(h, p, scratch8, gelu_table, dy_main, dy_res, x16, out, M, scale, bias_int, sc, ln_dy);
 }
 
 }  // extern "C"

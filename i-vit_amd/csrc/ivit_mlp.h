@@ -74,6 +74,11 @@ struct MlpArgs {
     long long M;
     int balanced;             // unit schedule: 0 = 64-token units dealt round-robin, 1 = contiguous tile ranges cut into units of <= 5 tiles
     unsigned long long *trace;   // MLP_TRACE builds only
+    // mlp384rs_kernel<FMA, LNH = true> (ivit_layernorm_mlp_fused_planned): norm2 + qact3 of this workgroup's rows first, from the block's 16-bit
+    // stream (`residual` is that stream), into x (a scratch of M x 384 bytes that only this launch reads)
+    float ln_s;
+    const float *ln_bias_int, *ln_sc;
+    const ivit_dyadic *ln_dy;
 };
 
 __device__ __forceinline__ int mlp_phi(int tok, int chunk) {

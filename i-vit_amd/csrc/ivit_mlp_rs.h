@@ -29,6 +29,7 @@
 // ds_write_b128 (eight consecutive tokens per group, 32 banks).
 #pragma once
 #include "ivit_mlp.h"
+#include "ivit_layernorm.h"
 
 #define RS_T 80                                  // token rows of a unit in LDS (5 tiles of 16)
 #define RS_KBLK (RS_T * 64)
@@ -123,7 +124,7 @@ __device__ __forceinline__ void rs_wait(unsigned flag_addr, unsigned target) {
                  : "=&v"(v), "=&s"(cnt), "=&s"(tmp) : "v"(flag_addr), "s"(target) : "memory", "scc");
 }
 
-template <bool FMA>
+template <bool FMA, bool LNH = false>
 __global__ __launch_bounds__(RS_THREADS, 2) void mlp384rs_kernel(MlpArgs p) {
     extern __shared__ __attribute__((aligned(256))) char sm[];
     typedef double v2d __attribute__((ext_vector_type(2)));
@@ -163,6 +164,38 @@ __global__ __launch_bounds__(RS_THREADS, 2) void mlp384rs_kernel(MlpArgs p) {
 
     if (threadIdx.x < 32) reinterpret_cast<unsigned *>(sm + RS_SFLAG)[threadIdx.x] = 0;
     if (threadIdx.x < 96) reinterpret_cast<int *>(sm + RS_SMAX)[threadIdx.x] = (int)0x80000000;
+    if constexpr (LNH) {
+        // ---- norm2 + qact3 (vit_quant.py:139-140) of the rows this workgroup will multiply, by all eight waves, 8 rows per wave and pass
+        // (LnGroup<384, 2>: layernorm_reg_kernel's arithmetic), into the 8-bit scratch p.x; the units below fetch their activation tiles from
+        // it (L2) as before.  The LayerNorm's constants borrow the hidden tile, which nobody touches before the first producer flush
+        typedef LnGroup<MLP_C, 2> G;
+        double *cC = reinterpret_cast<double *>(sm + RS_SH);
+        float *cB = reinterpret_cast<float *>(sm + RS_SH + MLP_C * 8), *cSc = cB + MLP_C, *cY = cSc + MLP_C;
+        const bool ln_fast = ln_stage_constants<MLP_C, RS_THREADS>(p.ln_bias_int, p.ln_sc, p.ln_dy, cC, cB, cSc, cY);
+        const int lane = threadIdx.x & 63, j = lane & 7, k = j >> 1, hh = j & 1;
+        const float ys = rcp_rn(p.ln_s);
+        int8_t *a8 = const_cast<int8_t *>(p.x);
+        const int nrange = p.balanced ? 1 : nu;            // contiguous tiles, or one 64-token unit at a time
+        for (int ri = 0; ri < nrange; ++ri) {
+            const long long r_beg = (p.balanced ? t_beg : unit_tile0(ri)) * 16;
+            const long long r_end = min((p.balanced ? t_end : unit_tile0(ri) + unit_ntt(ri)) * 16, p.M);
+            for (long long r0 = r_beg + wave * 8; r0 < r_end; r0 += 64) {
+                const long long row_raw = r0 + (lane >> 3);
+                const bool live = row_raw < r_end;
+                const long long row = live ? row_raw : r_end - 1;
+                const int16_t *xp = p.residual + row * MLP_C + 8 * k + 4 * hh;
+                float xv[G::NSTEP][G::EPC];
+#pragma unroll
+                for (int i = 0; i < G::NSTEP; ++i) {
+                    const LnRaw<4>::T t = *reinterpret_cast<const LnRaw<4>::T *>(xp + 32 * i);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) xv[i][c] = requotient_m((float)t[c], p.ln_s, ys);
+                }
+                G::run(xv, j, k, 8 * k + 4 * hh, ln_fast, live, cC, cB, cSc, cY, p.ln_bias_int, p.ln_sc, p.ln_dy, a8 + row * MLP_C + 8 * k + 4 * hh);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's bytes are in the L2 before anybody's DMA asks for them
+    }
     __syncthreads();
 
     // activation tile of a unit: global -> LDS by DMA, 16 tokens x 4 chunk slots per instruction; the source chunk of a

@@ -43,6 +43,9 @@ struct ivit_graph_s {
 #define IVIT_OPT_PROJ_LN 0              // A/B: norm2 in the tail of the attn.proj launch (ivit_linear_i8_requant_residual_layernorm_planned): same-box
                                        // 2.785 ms against 2.657 with norm2 as its own launch (the tail runs behind a barrier, two waves per SIMD)
 #endif
+#ifndef IVIT_OPT_LN_MLP
+#define IVIT_OPT_LN_MLP 1              // A/B: norm2 in the head of the fused Mlp's launch (ivit_layernorm_mlp_fused_planned)
+#endif
 #ifndef IVIT_OPT_ATTN_ROWTAB
 #define IVIT_OPT_ATTN_ROWTAB 1         // A/B: Shiftmax by row tables (one gather per score) where a layer's table lines fit
 #endif
@@ -144,21 +147,27 @@ int run_slice(const ivit_vit_s *m, ivit_handle h, const int8_t *images, int B, i
             RUN(ivit_shiftmax(h, s8, (int64_t)B * H * T, T, ld, b.s_softmax, 16, p16, ld));
             RUN(ivit_attn_pv_requant(h, p16, vt, b.dy_pv, ctx8, B, H, T, dh, ld, ld));
         }
-        // attn.proj + qact2 with the identity branch; norm2 + qact3 on the rows it produced can ride in the same launch (the kernel
-        // owns whole rows per workgroup) — built, bit-exact, measured slower than its own launch and switched off (IVIT_OPT_PROJ_LN)
+        // attn.proj + qact2 with the identity branch, then norm2 + qact3 and the Mlp.  norm2 can ride in the TAIL of the proj launch (the kernel
+        // owns whole rows per workgroup: built, bit-exact, slower, IVIT_OPT_PROJ_LN = 0) or in the HEAD of the fused Mlp's launch
+        // (ivit_layernorm_mlp_fused_planned, IVIT_OPT_LN_MLP)
+        const bool mlp_fast = m->mlp_plans[i] && fabs(b.res2_main.m * b.res2_main.r) < RQ_FAST_CLIM &&
+                              fabs(b.res2_res.m * b.res2_res.r) < RQ_FAST_CLIM;
         rc = IVIT_OPT_PROJ_LN ? ivit_linear_i8_requant_residual_layernorm_planned(h, m->plans[4 * i + 1], ctx8, b.res1_main, b.res1_res, x, y, M,
                                                                                 b.s_ln2, b.n2_bias_int, b.n2_sc, b.n2_dy, a8)
                               : IVIT_ERR_UNSUPPORTED;
-        if (rc == IVIT_ERR_UNSUPPORTED) {
-            RUN(ivit_linear_i8_requant_residual_planned(h, m->plans[4 * i + 1], ctx8, b.res1_main, b.res1_res, x, y, M));
-            RUN(ivit_layernorm_requant(h, y, M, D, D, b.s_ln2, b.n2_bias_int, b.n2_sc, b.n2_dy, a8));
-        } else {
-            RUN(rc);
-        }
+        bool ln2_done = rc != IVIT_ERR_UNSUPPORTED;
+        if (!ln2_done) RUN(ivit_linear_i8_requant_residual_planned(h, m->plans[4 * i + 1], ctx8, b.res1_main, b.res1_res, x, y, M));
+        else RUN(rc);
         { int16_t *t = x; x = y; y = t; }
-        const bool mlp_fast = m->mlp_plans[i] && fabs(b.res2_main.m * b.res2_main.r) < RQ_FAST_CLIM &&
-                              fabs(b.res2_res.m * b.res2_res.r) < RQ_FAST_CLIM;
-        if (mlp_fast) {     // hidden tensor stays in LDS
+        bool mlp_done = false;
+        if (!ln2_done && mlp_fast && IVIT_OPT_LN_MLP) {
+            rc = ivit_layernorm_mlp_fused_planned(h, m->mlp_plans[i], x, b.s_ln2, b.n2_bias_int, b.n2_sc, b.n2_dy, a8, m->gelu_tab + (size_t)i * 65536,
+                                                  b.res2_main, b.res2_res, y, M);
+            if (rc != IVIT_ERR_UNSUPPORTED) { RUN(rc); ln2_done = mlp_done = true; }
+        }
+        if (!ln2_done) RUN(ivit_layernorm_requant(h, x, M, D, D, b.s_ln2, b.n2_bias_int, b.n2_sc, b.n2_dy, a8));
+        if (mlp_done) {
+        } else if (mlp_fast) {     // hidden tensor stays in LDS
             RUN(ivit_mlp_fused_planned(h, m->mlp_plans[i], a8, m->gelu_tab + (size_t)i * 65536, b.res2_main, b.res2_res, x, y, M));
         } else {
             RUN(ivit_linear_i8_requant_planned(h, m->plans[4 * i + 2], a8, 8, h8, M));

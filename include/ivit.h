@@ -49,7 +49,8 @@ enum {
 };
 
 /* 100 * major + minor.  103 (round 6): ivit_linear_plan_prepare_ws, ivit_layernorm_linear_i8_qkv_planned,
- * ivit_linear_i8_requant_residual_layernorm_planned, ivit_layernorm_linear_i8_requant_planned, ivit_patch_embed (additions only).
+ * ivit_linear_i8_requant_residual_layernorm_planned, ivit_layernorm_linear_i8_requant_planned, ivit_patch_embed,
+ * ivit_layernorm_mlp_fused_planned (additions only).
  * 102 (round 6): ivit_shiftmax_rowtable, ivit_attention_fused_rowlut (additions only).
  * 101 (round 5): ivit_mlp_plan_select; ivit_swin_block / ivit_vit_block carry the optional Shiftmax-table
  * fields exp_* at their END (added in 100 without a bump: a caller compiled against an older layout must be rebuilt).
@@ -490,6 +491,14 @@ int ivit_mlp_plan_select(ivit_mlp_plan p, int kernel);
 int ivit_mlp_fused_planned(ivit_handle h, ivit_mlp_plan p, const int8_t *x, const int8_t *gelu_table,
                            ivit_dyadic dy_main, ivit_dyadic dy_res, const int16_t *residual, int16_t *out,
                            int64_t M);
+/* Round 6: norm2 + qact3 + the fused Mlp + the block's residual QuantAct in ONE launch (vit_quant.py:139-142): every workgroup first
+ * normalises the rows it is going to multiply (x16 [M, 384], the block's 16-bit stream, which is also the identity branch; scale /
+ * bias_int / sc / ln_dy as for ivit_layernorm_requant) into scratch8 [M, 384] and reads its activation tiles from there.  out ==
+ * ivit_layernorm_requant followed by ivit_mlp_fused_planned.  IVIT_ERR_UNSUPPORTED (nothing launched) where ivit_mlp_fused_planned is,
+ * and where the launch would run on the lock-step kernel (fewer than two units per CU).                                        */
+int ivit_layernorm_mlp_fused_planned(ivit_handle h, ivit_mlp_plan p, const int16_t *x16, float scale, const float *bias_int,
+                                     const float *sc, const ivit_dyadic *ln_dy, int8_t *scratch8, const int8_t *gelu_table,
+                                     ivit_dyadic dy_main, ivit_dyadic dy_res, int16_t *out, int64_t M);
 /* PatchMerging's 2x2 gather (swin_quant.py:336-342): x [B,R,R,C] (in_bits 8 or 16) ->
  * int16 [B, (R/2)^2, 4C], channel blocks in the reference's torch.cat order.                  */
 int ivit_patch_merge_gather(ivit_handle h, const void *x, int in_bits, int B, int R, int C, int16_t *out);

@@ -703,6 +703,50 @@ def test_mlp_fused_planned_vs_oracle_production_geometry(M, mlp_production_case)
         H.lib.ivit_linear_plan_destroy(pl)
 
 
+@pytest.mark.parametrize("M", [80 * 256 + 1, 25216, 40961, 50176, 50432, 100000])
+def test_layernorm_mlp_fused_equals_two_launches(M, mlp_production_case):
+    """norm2 + qact3 in the head of the fused Mlp's launch (ivit_layernorm_mlp_fused_planned, mlp384rs_kernel<.., LNH>; vit_quant.py:139-142)
+    == ivit_layernorm_requant followed by ivit_mlp_fused_planned (both pinned against the oracle above), bit for bit, on the 16-bit stream
+    that is LayerNorm input AND identity branch: the balanced and the round-robin unit schedules, ragged last rows, guard rows behind the
+    output and behind the scratch; refused (nothing launched) where the launch would run on the lock-step kernel."""
+    c = mlp_production_case
+    C, Hd, dyv = c["C"], c["Hd"], c["dyv"]
+    H = _lib.Handle(0, torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(M)
+    tabd = torch.empty(65536, dtype=torch.int8, device="cuda")
+    H.call("ivit_shiftgelu_build_table", 0.04, dyv(c["dg"]), _P(tabd.data_ptr()))
+    d = {k: torch.from_numpy(np.ascontiguousarray(c[k])).cuda() for k in ("w1", "b1", "w2", "b2", "d1", "d2")}
+    x16 = rng.integers(-20000, 20000, (M, C)).astype(np.int16)
+    x16[:, : C // 2] //= 64
+    x16 = torch.from_numpy(x16).cuda()
+    wln = rng.normal(1.0, 0.4, C).astype(np.float32) * rng.choice([-1.0, 1.0], C).astype(np.float32)
+    bias_int, sc = iv.freeze.layernorm_constants(wln, rng.normal(0.0, 0.5, C).astype(np.float32))
+    s_in = np.float32(2.5e-4)
+    bi_d, sc_d = torch.from_numpy(bias_int).cuda(), torch.from_numpy(sc).cuda()
+    dln = torch.from_numpy(iv.freeze.dyadic(sc, np.float32(0.031))).cuda()
+    g1, g2, gm = (_P() for _ in range(3))
+    H.call("ivit_linear_plan_create", _P(d["w1"].data_ptr()), _P(d["b1"].data_ptr()), _P(d["d1"].data_ptr()), Hd, C, ctypes.byref(g1))
+    H.call("ivit_linear_plan_create", _P(d["w2"].data_ptr()), _P(d["b2"].data_ptr()), _P(d["d2"].data_ptr()), C, Hd, ctypes.byref(g2))
+    H.call("ivit_mlp_plan_create", g1, g2, ctypes.byref(gm))
+    a8 = torch.empty(M, C, dtype=torch.int8, device="cuda")
+    H.call("ivit_layernorm_requant", _P(x16.data_ptr()), M, C, C, float(s_in), _P(bi_d.data_ptr()), _P(sc_d.data_ptr()), _P(dln.data_ptr()), _P(a8.data_ptr()))
+    want = torch.full((M + 1, C), 0x5555, dtype=torch.int16, device="cuda")
+    H.call("ivit_mlp_fused_planned", gm, _P(a8.data_ptr()), _P(tabd.data_ptr()), dyv(c["dm"]), dyv(c["dr"]), _P(x16.data_ptr()), _P(want.data_ptr()), M)
+    got = torch.full((M + 1, C), 0x5555, dtype=torch.int16, device="cuda")
+    scratch = torch.full((M + 1, C), 77, dtype=torch.int8, device="cuda")
+    args = (gm, _P(x16.data_ptr()), float(s_in), _P(bi_d.data_ptr()), _P(sc_d.data_ptr()), _P(dln.data_ptr()), _P(scratch.data_ptr()), _P(tabd.data_ptr()),
+            dyv(c["dm"]), dyv(c["dr"]), _P(got.data_ptr()), M)
+    H.call("ivit_layernorm_mlp_fused_planned", *args)
+    assert torch.equal(got, want), int((got != want).sum())
+    assert torch.equal(scratch[:M], a8) and (scratch[M] == 77).all() and len(torch.unique(want)) > 5000
+    assert H.lib.ivit_mlp_plan_select(gm, 1) == 0            # pinned to the lock-step kernel: refused
+    with pytest.raises(_lib.IvitError, match="role-split"):
+        H.call("ivit_layernorm_mlp_fused_planned", *args)
+    H.lib.ivit_mlp_plan_destroy(gm)
+    for pl in (g1, g2):
+        H.lib.ivit_linear_plan_destroy(pl)
+
+
 # ---------------------------------------------------------------- calibration (SURVEY §8f N1)
 CALIB_BATCH = {"micro_vit_b2.npz": 4, "micro_vit2h_b3.npz": 4, "deit_tiny_b1.npz": 2, "micro_swin_b2.npz": 4}
 # What is pinned per fixture (measured with tools/calib_diag.py): the FIRST QuantAct site, in forward order, whose calibrated
