@@ -408,6 +408,9 @@ struct ivit_swin_s {
 #ifndef IVIT_OPT_SWIN_WS
 #define IVIT_OPT_SWIN_WS 1             // A/B: the C = 384 stage's qkv (+ norm1) and proj layers on gemm_ws_qkv_kernel
 #endif
+#ifndef IVIT_OPT_SWIN_LN_MLP
+#define IVIT_OPT_SWIN_LN_MLP 0
+#endif
 #ifndef IVIT_OPT_SWIN_PLANS
 #define IVIT_OPT_SWIN_PLANS 0          // A/B: the C = 384 / 768 stages' QuantLinear layers on the planned (persistent) kernels
 #endif
@@ -489,10 +492,19 @@ int swin_run_slice(const ivit_swin_s *m, ivit_handle h, const int8_t *images, in
             if (lp && lp[1]) RUN(ivit_linear_i8_requant_residual_planned(h, lp[1], ctx, b.res1_main, b.res1_res, x, y, (int)M));
             else RUN(ivit_linear_i8_requant_residual(h, ctx, b.proj.w, b.proj.b, b.proj.dy, b.res1_main, b.res1_res, x, y, (int)M, C, C));
             { int16_t *t = x; x = y; y = t; }
-            RUN(swin_ln(m, h, x, M, C, b.s_mid, b.n2, L, li == 0, a8));
             const bool mlp384 = m->mlp_plans[bi] && fabs(b.res2_main.m * b.res2_main.r) < RQ_FAST_CLIM &&
                                 fabs(b.res2_res.m * b.res2_res.r) < RQ_FAST_CLIM;
-            if (C == 96 && c.mlp_ratio == 4 && m->fused_mlp) {     // narrow stage: hidden tensor stays in LDS
+            // C = 384 stage: norm2 can ride in the head of the fused Mlp's launch (natural token order) — measured SLOWER here (Swin-T b256,
+            // two slices: 4.76 against 4.70 ms same-box; the LayerNorm launch of one slice overlaps the other slice's kernels) and off
+            rc = (IVIT_OPT_SWIN_LN_MLP && mlp384 && li != 0)
+                     ? ivit_layernorm_mlp_fused_planned(h, m->mlp_plans[bi], x, b.s_mid, b.n2.bias_int, b.n2.sc, b.n2.dy, a8,
+                                                        m->gelu_tab + (size_t)bi * 65536, b.res2_main, b.res2_res, y, M)
+                     : IVIT_ERR_UNSUPPORTED;
+            const bool ln_mlp = rc != IVIT_ERR_UNSUPPORTED;
+            if (ln_mlp) RUN(rc);
+            else RUN(swin_ln(m, h, x, M, C, b.s_mid, b.n2, L, li == 0, a8));
+            if (ln_mlp) {
+            } else if (C == 96 && c.mlp_ratio == 4 && m->fused_mlp) {     // narrow stage: hidden tensor stays in LDS
                 RUN(ivit_mlp_fused(h, a8, b.fc1.w, b.fc1.b, b.fc1.dy, m->gelu_tab + (size_t)bi * 65536, b.fc2.w, b.fc2.b,
                                    b.fc2.dy, b.res2_main, b.res2_res, x, y, M, C, 4 * C));
             } else if (mlp384) {                                    // C = 384 stage: weights streamed, hidden tile in LDS
