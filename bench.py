@@ -459,8 +459,9 @@ def main():
         lin_ops, bmm_ops = (vit_ops_per_image if family == "vit" else swin_ops_per_image)(cfg)
         # (round 6: the qkv layer of a D = 384 block carries norm1 in its prologue — ivit_layernorm_linear_i8_qkv_planned; the whole
         # launch, LayerNorm included, is inside the time the class's OPs are divided by)
-        is_gemm = lambda n: n.startswith("ivit_linear_i8") or n.startswith("ivit_mlp_fused") or n == "ivit_layernorm_linear_i8_qkv_planned"
-        ln_fused = "ivit_layernorm_linear_i8_qkv_planned" in per
+        is_gemm = lambda n: (n.startswith("ivit_linear_i8") or n.startswith("ivit_mlp_fused") or n == "ivit_patch_embed" or
+                             n in ("ivit_layernorm_linear_i8_qkv_planned", "ivit_layernorm_mlp_fused_planned"))
+        ln_fused = int("ivit_layernorm_linear_i8_qkv_planned" in per) + int("ivit_layernorm_mlp_fused_planned" in per)
         g_ms = sum(v[0] for n, v in per.items() if is_gemm(n)) / ps
         g_n = sum(v[1] for n, v in per.items() if is_gemm(n)) / ps
         achieved = (lin_ops * batch / (g_ms * 1e-3) / 1e12) if g_ms > 0 else None
@@ -481,7 +482,7 @@ def main():
             # LayerNorm + requant int16 -> int8 3 B/elem; ShiftGELU + requant int8 -> int8 2 B/elem;
             # fused attention reads q, k, v and writes ctx: 4 B per (token, channel)
             # (norm1 of a block whose qkv launch computes it is not a LayerNorm launch any more)
-            hbm_ops["layernorm_requant"] = hbm("ivit_layernorm_requant", ((1 if ln_fused else 2) * cfg.depth * M + batch) * D * 3)
+            hbm_ops["layernorm_requant"] = hbm("ivit_layernorm_requant", ((2 - ln_fused) * cfg.depth * M + batch) * D * 3)
             # ShiftGELU is a launch of its own only where the Mlp is not fused (D != 384)
             hbm_ops["shiftgelu_requant"] = hbm("ivit_shiftgelu_requant_lut", cfg.depth * M * Hd * 2)
             # fused attention is bound by NEITHER roofline (VALU / LDS chains per score): both fractions are printed, outside
@@ -529,6 +530,8 @@ def main():
             M = batch * T
             fused = "ivit_mlp_fused_planned" in per
             ops_of = {"ivit_mlp_fused_planned": ("fc1 + ShiftGELU + fc2 + residual in one launch (mlp384rs_kernel / mlp384_kernel)", 4.0 * M * D * Hd),
+                      "ivit_layernorm_mlp_fused_planned": ("norm2 + fc1 + ShiftGELU + fc2 + residual in one launch (mlp384rs_kernel<.., LNH>: the LayerNorm's "
+                                                           "time is inside, its operations are not counted)", 4.0 * M * D * Hd),
                       "ivit_linear_i8_qkv_planned": ("qkv QuantLinear (gemm_as_kernel<5> / gemm_ws_qkv_kernel)", 6.0 * M * D * D),
                       "ivit_layernorm_linear_i8_qkv_planned": ("norm1 + qkv QuantLinear in one launch (gemm_ws_qkv_kernel<.., LN>: the LayerNorm's "
                                                                "time is inside, its operations are not counted)", 6.0 * M * D * D),
@@ -546,7 +549,8 @@ def main():
         roofline = {
             "kernel": "QuantLinear GEMM class: gemm_ws_qkv_kernel (D = 384: norm1 + qkv in one launch, proj + residual), gemm_as_kernel / gemm_ps_kernel / "
                       "gemm_glds_kernel (patch-embed, qkv, proj, head; fused requant epilogues) and mlp384rs_kernel / mlp384_kernel (fc1 + ShiftGELU + fc2 + "
-                      "residual QuantAct in one launch where D = 384); the ShiftGELU table pass and the fused norm1 are inside the time the OPs are divided by",
+                      "residual QuantAct in one launch where D = 384, norm2 in its head); the ShiftGELU table pass, both fused LayerNorms and the patch gather are "
+                      "inside the time the OPs are divided by",
             "bound": "mfma", "achieved": None if achieved is None else round(achieved, 1),
             "peak": INT8_PEAK_TOPS, "unit": "TOP/s",
             "frac": None if achieved is None else round(achieved / INT8_PEAK_TOPS, 4),
@@ -563,6 +567,12 @@ def main():
             "launches_per_step": g_n, "ms_per_step_in_kernel": round(g_ms, 4),
             "avg_launch_ms": round(g_ms / g_n, 5) if g_n else None,
             "algorithmic_ops_per_step": lin_ops * batch,
+            # every int8 MAC of the forward (QuantLinear + attention matmuls) over the TIMED step — the product path, whatever it fuses:
+            # the one fraction that stays comparable when a LayerNorm moves into a GEMM launch (the class fraction above then drops,
+            # because that launch's time now includes the LayerNorm)
+            "whole_model": {"algorithmic_ops_per_step": (lin_ops + bmm_ops) * batch,
+                            "achieved": round((lin_ops + bmm_ops) * batch / (ms_per_step * 1e-3) / 1e12, 1), "peak": INT8_PEAK_TOPS,
+                            "unit": "TOP/s per GPU", "frac": round((lin_ops + bmm_ops) * batch / (ms_per_step * 1e-3) / 1e12 / INT8_PEAK_TOPS, 4)},
             # register-only MFMA loops on random int8 operands, measured by THIS run on THIS box (`box` below): the chip clocks
             # down to ~1.7-2.0 GHz under int8 MFMA load, so the nominal 5033 is not reachable by any kernel
             "mfma_ubench_ceiling_tops_random_operands": (box or {}).get("mfma_tops_random"),

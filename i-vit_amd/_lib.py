@@ -28,6 +28,9 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
                "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 
 
+IVIT_OK, IVIT_ERR_INVALID, IVIT_ERR_HIP, IVIT_ERR_UNSUPPORTED, IVIT_ERR_NO_DEVICE = 0, 1, 2, 3, 4      # include/ivit.h
+
+
 class IvitError(RuntimeError):
     pass
 
@@ -283,6 +286,22 @@ class Handle:
 
     def call(self, name, *args):
         self._check(getattr(self.lib, name)(self.h, *args), name)
+
+    def try_call(self, name, *args):
+        """call(), but IVIT_ERR_UNSUPPORTED (the entry point refused the shape and launched nothing) returns False instead of raising."""
+        self.unsupported = False
+
+        def check(st, nm):
+            if st == IVIT_ERR_UNSUPPORTED:
+                self.unsupported = True
+            else:
+                self._check_plain(st, nm)
+        self._check_plain, self._check = self._check, check
+        try:
+            self.call(name, *args)          # through self.call: a timing wrapper installed on it sees this launch too
+        finally:
+            self._check = self._check_plain
+        return not self.unsupported
 
     def linear_plan(self, w, bias, dy, N, K):
         """ivit_linear_plan_create: returns a LinearPlan (frozen QuantLinear: w/bias/dy device pointers must outlive it)."""

@@ -126,6 +126,8 @@ class ViTEngine:
         self.use_row_tables = True
         self.v_row_major = True         # forward_ops: v row-major into the row-table attention (False: v^T as before)
         self.fuse_ln_qkv = True         # forward_ops: norm1 in the qkv GEMM's prologue where the plan is prepared (False: two launches)
+        self.fuse_ln_mlp = True         # forward_ops: norm2 in the head of the fused Mlp's launch (False: two launches)
+        self.fuse_patch_embed = True    # forward_ops: ivit_patch_embed (False: im2col, GEMM, embed_finish)
         self._qkv_prepared = set()
         self.rowtab = {}
         if self.fused_attention:
@@ -319,14 +321,20 @@ class ViTEngine:
         ld = ws["ld"]
         P = lambda t: _P(t.data_ptr())
         Kp = cfg.in_chans * cfg.patch_size ** 2
-        call("ivit_im2col_patch", P(images), B, cfg.in_chans, cfg.img_size, cfg.img_size, cfg.patch_size,
-             P(ws["patches"]))
-        call("ivit_linear_i8_requant", P(ws["patches"]), self.ptr("patch_embed.proj.w"),
-             self.ptr("patch_embed.proj.b"), self.ptr("patch_embed.proj.dy"), 16, P(ws["patch16"]),
-             B * cfg.num_patches, D, Kp)
         x, y = ws["xa"], ws["xb"]
-        call("ivit_embed_finish", P(ws["patch16"]), self.ptr("z_cls"), self.ptr("pos"), _dy(hc["embed.dy_x"]),
-             _dy(hc["embed.dy_pos"]), P(x), B, T, D)
+        # the runner's choice: the whole PatchEmbed front end as one GEMM launch where it applies (16 x 16 patches, fast multipliers)
+        one = self.fuse_patch_embed and self.h.try_call(
+            "ivit_patch_embed", P(images), B, cfg.in_chans, cfg.img_size, cfg.img_size, cfg.patch_size, self.ptr("patch_embed.proj.w"),
+            self.ptr("patch_embed.proj.b"), self.ptr("patch_embed.proj.dy"), self.ptr("z_cls"), self.ptr("pos"), _dy(hc["embed.dy_x"]),
+            _dy(hc["embed.dy_pos"]), P(x), D)
+        if not one:
+            call("ivit_im2col_patch", P(images), B, cfg.in_chans, cfg.img_size, cfg.img_size, cfg.patch_size,
+                 P(ws["patches"]))
+            call("ivit_linear_i8_requant", P(ws["patches"]), self.ptr("patch_embed.proj.w"),
+                 self.ptr("patch_embed.proj.b"), self.ptr("patch_embed.proj.dy"), 16, P(ws["patch16"]),
+                 B * cfg.num_patches, D, Kp)
+            call("ivit_embed_finish", P(ws["patch16"]), self.ptr("z_cls"), self.ptr("pos"), _dy(hc["embed.dy_x"]),
+                 _dy(hc["embed.dy_pos"]), P(x), B, T, D)
         for i in range(cfg.depth):
             p = f"blocks.{i}."
             # the runner's choice (csrc/ivit_model.h): v ROW-major (ldv = 0) between the planned qkv GEMM and the row-table attention
@@ -373,12 +381,19 @@ class ViTEngine:
                 call("ivit_linear_i8_requant_residual", P(ws["ctx8"]), self.ptr(p + "attn.proj.w"), self.ptr(p + "attn.proj.b"),
                      self.ptr(p + "attn.proj.dy"), _dy(hc[p + "res1.dy_main"]), _dy(hc[p + "res1.dy_res"]), P(x), P(y), M, D, D)
             x, y = y, x
-            call("ivit_layernorm_requant", P(x), M, D, D, f32[p + "ln2.s"], self.ptr(p + "norm2.bias_int"),
-                 self.ptr(p + "norm2.sc"), self.ptr(p + "norm2.dy"), P(ws["a8"]))
             dm, dr = hc[p + "res2.dy_main"], hc[p + "res2.dy_res"]
             fused = (self.use_plans and self.use_fused_mlp and i in self._mlp_plans
                      and abs(dm[0, 0] * dm[0, 1]) < 512.0 and abs(dr[0, 0] * dr[0, 1]) < 512.0)
-            if fused:       # the runner's choice (csrc/ivit_model.h): hidden tensor never in HBM
+            # the runner's choice: norm2 in the head of the fused Mlp's launch where that launch runs on the role-split kernel
+            ln_mlp = fused and self.fuse_ln_mlp and self.h.try_call(
+                "ivit_layernorm_mlp_fused_planned", self._mlp_plans[i], P(x), f32[p + "ln2.s"], self.ptr(p + "norm2.bias_int"), self.ptr(p + "norm2.sc"),
+                self.ptr(p + "norm2.dy"), P(ws["a8"]), _P(self.gelu_tab[i].data_ptr()), _dy(dm), _dy(dr), P(y), M)
+            if not ln_mlp:
+                call("ivit_layernorm_requant", P(x), M, D, D, f32[p + "ln2.s"], self.ptr(p + "norm2.bias_int"),
+                     self.ptr(p + "norm2.sc"), self.ptr(p + "norm2.dy"), P(ws["a8"]))
+            if ln_mlp:
+                pass
+            elif fused:       # hidden tensor never in HBM
                 call("ivit_mlp_fused_planned", self._mlp_plans[i], P(ws["a8"]), _P(self.gelu_tab[i].data_ptr()), _dy(dm), _dy(dr),
                      P(x), P(y), M)
             elif self.use_plans:

@@ -452,8 +452,8 @@ def test_vit_forward_golden_logits(fname):
     assert np.array_equal(eng.forward_ops(d_imgs).cpu().numpy(), g["logits_int"])
     if fname == "deit_small_b4.npz":
         # round 6: the D = 384, dh = 64 model takes norm1 inside the qkv GEMM's prologue; the two-launch form gives the same integers
-        assert eng._qkv_prepared and eng.fuse_ln_qkv
-        eng.fuse_ln_qkv = False
+        assert eng._qkv_prepared and eng.fuse_ln_qkv and eng.fuse_ln_mlp and eng.fuse_patch_embed
+        eng.fuse_ln_qkv = eng.fuse_ln_mlp = eng.fuse_patch_embed = False       # every layer as its own launches: the same integers
         assert np.array_equal(eng.forward_ops(d_imgs).cpu().numpy(), g["logits_int"])
     else:
         assert not eng._qkv_prepared
