@@ -798,6 +798,9 @@ int ivit_layernorm_linear_i8_qkv_planned(ivit_handle h, ivit_linear_plan pl, con
 #ifndef IVIT_OPT_MLP_RS
 #define IVIT_OPT_MLP_RS 1               // A/B builds: 0 = the shape-based default never picks the role-split kernel
 #endif
+#ifndef IVIT_OPT_MLP_LNH
+#define IVIT_OPT_MLP_LNH 1               // ivit_layernorm_mlp_fused_planned: 1 = the LayerNorm of every row first, 2 = the first unit's rows first, the rest
+#endif                                   // by the consumer waves beside the producers' first fc1 (bit-exact, 2.69 against 2.65 ms per forward: not the default)
 struct ivit_mlp_plan_s {
     ivit_linear_plan fc1, fc2;      // borrowed: must outlive this plan
     v4i *w1f, *w2f;                 // fragment-ordered copies of the two weight matrices (one allocation)
@@ -842,7 +845,7 @@ int ivit_mlp_plan_create(ivit_handle h, ivit_linear_plan fc1, ivit_linear_plan f
     {   // the dynamic-LDS attributes of the kernels this plan will launch: once, here
         const void *fn = p->fma ? (const void *)mlp384_kernel<true> : (const void *)mlp384_kernel<false>;
         const void *fr = p->fma ? (const void *)mlp384rs_kernel<true> : (const void *)mlp384rs_kernel<false>;
-        const void *fl = p->fma ? (const void *)mlp384rs_kernel<true, true> : (const void *)mlp384rs_kernel<false, true>;
+        const void *fl = p->fma ? (const void *)mlp384rs_kernel<true, IVIT_OPT_MLP_LNH> : (const void *)mlp384rs_kernel<false, IVIT_OPT_MLP_LNH>;
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_SMEM);
         if (e == hipSuccess) e = hipFuncSetAttribute(fr, hipFuncAttributeMaxDynamicSharedMemorySize, RS_SMEM);
         if (e == hipSuccess) e = hipFuncSetAttribute(fl, hipFuncAttributeMaxDynamicSharedMemorySize, RS_SMEM);
@@ -902,8 +905,8 @@ static int mlp_fused_launch(ivit_handle h, ivit_mlp_plan p, const int8_t *x, con
     if (role_split) {
         a.w1f = p->w1r; a.w2f = p->w2r;
         if (ln_dy) {
-            if (p->fma) mlp384rs_kernel<true, true><<<grid, RS_THREADS, RS_SMEM, h->stream>>>(a);
-            else mlp384rs_kernel<false, true><<<grid, RS_THREADS, RS_SMEM, h->stream>>>(a);
+            if (p->fma) mlp384rs_kernel<true, IVIT_OPT_MLP_LNH><<<grid, RS_THREADS, RS_SMEM, h->stream>>>(a);
+            else mlp384rs_kernel<false, IVIT_OPT_MLP_LNH><<<grid, RS_THREADS, RS_SMEM, h->stream>>>(a);
         } else if (p->fma) mlp384rs_kernel<true><<<grid, RS_THREADS, RS_SMEM, h->stream>>>(a);
         else mlp384rs_kernel<false><<<grid, RS_THREADS, RS_SMEM, h->stream>>>(a);
     } else if (p->fma) mlp384_kernel<true><<<grid, MLP_THREADS, MLP_SMEM, h->stream>>>(a);

@@ -46,6 +46,7 @@
 #define RS_F_A 2
 #define RS_F_D 3
 #define RS_F_R 4                                 // .. 15
+#define RS_F_L 16                                // LNH = 2: consumers done with the LayerNorm of units 1 ..
 #ifndef RS_WR
 #define RS_WR 9                                  // producer: slots of the weight-fragment ring (RS_WR - 1 k-steps in flight); divides 12 * RS_HD
 #endif
@@ -124,7 +125,9 @@ __device__ __forceinline__ void rs_wait(unsigned flag_addr, unsigned target) {
                  : "=&v"(v), "=&s"(cnt), "=&s"(tmp) : "v"(flag_addr), "s"(target) : "memory", "scc");
 }
 
-template <bool FMA, bool LNH = false>
+// LNH: 0 = the activations are 8-bit (p.x); 1 = norm2 of every row of the workgroup first, by all eight waves; 2 = only the first unit's rows
+// first, the rest by the four consumer waves beside the producers' fc1 of the first unit (the consumers then do not help with that fc1)
+template <bool FMA, int LNH = 0>
 __global__ __launch_bounds__(RS_THREADS, 2) void mlp384rs_kernel(MlpArgs p) {
     extern __shared__ __attribute__((aligned(256))) char sm[];
     typedef double v2d __attribute__((ext_vector_type(2)));
@@ -159,41 +162,52 @@ __global__ __launch_bounds__(RS_THREADS, 2) void mlp384rs_kernel(MlpArgs p) {
         }
     };
     // cumulative hand-over targets: in the first unit the consumers produce too (RS_HELP)
-    constexpr unsigned NP0 = RS_HELP ? 8 : 4, NG = RS_GSPLIT ? 8 : 4;
+    constexpr bool HELP = RS_HELP && LNH != 2;
+    constexpr unsigned NP0 = HELP ? 8 : 4, NG = RS_GSPLIT ? 8 : 4;
     auto fh_target = [&](int u) -> unsigned { return NP0 + 4u * (unsigned)u; };      // F_H / F_A after unit u
 
     if (threadIdx.x < 32) reinterpret_cast<unsigned *>(sm + RS_SFLAG)[threadIdx.x] = 0;
     if (threadIdx.x < 96) reinterpret_cast<int *>(sm + RS_SMAX)[threadIdx.x] = (int)0x80000000;
-    if constexpr (LNH) {
-        // ---- norm2 + qact3 (vit_quant.py:139-140) of the rows this workgroup will multiply, by all eight waves, 8 rows per wave and pass
-        // (LnGroup<384, 2>: layernorm_reg_kernel's arithmetic), into the 8-bit scratch p.x; the units below fetch their activation tiles from
-        // it (L2) as before.  The LayerNorm's constants borrow the hidden tile, which nobody touches before the first producer flush
-        typedef LnGroup<MLP_C, 2> G;
-        double *cC = reinterpret_cast<double *>(sm + RS_SH);
-        float *cB = reinterpret_cast<float *>(sm + RS_SH + MLP_C * 8), *cSc = cB + MLP_C, *cY = cSc + MLP_C;
-        const bool ln_fast = ln_stage_constants<MLP_C, RS_THREADS>(p.ln_bias_int, p.ln_sc, p.ln_dy, cC, cB, cSc, cY);
+    // ---- norm2 + qact3 (vit_quant.py:139-140) of the rows this workgroup will multiply (LnGroup<384, 2>: layernorm_reg_kernel's arithmetic,
+    // 8 rows per wave and pass), into the 8-bit scratch p.x; the units fetch their activation tiles from it (L2) as before.  The LayerNorm's
+    // constants sit in the ShiftGELU table-line slots, which nobody touches before the first ShiftGELU (LNH = 2: before F_L)
+    typedef LnGroup<MLP_C, 2> LG;
+    double *cC = reinterpret_cast<double *>(sm + RS_STAB);
+    float *cB = reinterpret_cast<float *>(sm + RS_STAB + MLP_C * 8), *cSc = cB + MLP_C, *cY = cSc + MLP_C;
+    static_assert(MLP_C * 20 <= 32 * 256, "the LayerNorm constants fit the table-line slots");
+    bool ln_fast = false;
+    // rows [r_beg, r_end) by `nw` waves, this one being number `w`
+    auto ln_rows = [&](long long r_beg, long long r_end, int w, int nw) __attribute__((always_inline)) {
         const int lane = threadIdx.x & 63, j = lane & 7, k = j >> 1, hh = j & 1;
         const float ys = rcp_rn(p.ln_s);
         int8_t *a8 = const_cast<int8_t *>(p.x);
-        const int nrange = p.balanced ? 1 : nu;            // contiguous tiles, or one 64-token unit at a time
-        for (int ri = 0; ri < nrange; ++ri) {
-            const long long r_beg = (p.balanced ? t_beg : unit_tile0(ri)) * 16;
-            const long long r_end = min((p.balanced ? t_end : unit_tile0(ri) + unit_ntt(ri)) * 16, p.M);
-            for (long long r0 = r_beg + wave * 8; r0 < r_end; r0 += 64) {
-                const long long row_raw = r0 + (lane >> 3);
-                const bool live = row_raw < r_end;
-                const long long row = live ? row_raw : r_end - 1;
-                const int16_t *xp = p.residual + row * MLP_C + 8 * k + 4 * hh;
-                float xv[G::NSTEP][G::EPC];
+        for (long long r0 = r_beg + w * 8; r0 < r_end; r0 += nw * 8) {
+            const long long row_raw = r0 + (lane >> 3);
+            const bool live = row_raw < r_end;
+            const long long row = live ? row_raw : r_end - 1;
+            const int16_t *xp = p.residual + row * MLP_C + 8 * k + 4 * hh;
+            float xv[LG::NSTEP][LG::EPC];
 #pragma unroll
-                for (int i = 0; i < G::NSTEP; ++i) {
-                    const LnRaw<4>::T t = *reinterpret_cast<const LnRaw<4>::T *>(xp + 32 * i);
+            for (int i = 0; i < LG::NSTEP; ++i) {
+                const LnRaw<4>::T t = *reinterpret_cast<const LnRaw<4>::T *>(xp + 32 * i);
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) xv[i][c] = requotient_m((float)t[c], p.ln_s, ys);
-                }
-                G::run(xv, j, k, 8 * k + 4 * hh, ln_fast, live, cC, cB, cSc, cY, p.ln_bias_int, p.ln_sc, p.ln_dy, a8 + row * MLP_C + 8 * k + 4 * hh);
+                for (int c = 0; c < 4; ++c) xv[i][c] = requotient_m((float)t[c], p.ln_s, ys);
             }
+            LG::run(xv, j, k, 8 * k + 4 * hh, ln_fast, live, cC, cB, cSc, cY, p.ln_bias_int, p.ln_sc, p.ln_dy, a8 + row * MLP_C + 8 * k + 4 * hh);
         }
+    };
+    // unit range [u0, u1) of this workgroup: contiguous rows in the balanced schedule, one 64-token unit at a time otherwise
+    auto ln_units = [&](int u0, int u1, int w, int nw) __attribute__((always_inline)) {
+        if (u0 >= u1) return;
+        if (p.balanced) {
+            ln_rows(unit_tile0(u0) * 16, min(unit_tile0(u1) * 16, p.M), w, nw);
+        } else {
+            for (int u = u0; u < u1; ++u) ln_rows(unit_tile0(u) * 16, min((unit_tile0(u) + unit_ntt(u)) * 16, p.M), w, nw);
+        }
+    };
+    if constexpr (LNH != 0) {
+        ln_fast = ln_stage_constants<MLP_C, RS_THREADS>(p.ln_bias_int, p.ln_sc, p.ln_dy, cC, cB, cSc, cY);
+        ln_units(0, LNH == 2 ? 1 : nu, wave, 8);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's bytes are in the L2 before anybody's DMA asks for them
     }
     __syncthreads();
@@ -324,6 +338,7 @@ __global__ __launch_bounds__(RS_THREADS, 2) void mlp384rs_kernel(MlpArgs p) {
         rs_signal(fl + 4 * RS_F_A);
         if (loader && next_ntt > 0) {
             rs_wait(fl + 4 * RS_F_A, fh_target(u));
+            if (LNH == 2) rs_wait(fl + 4 * RS_F_L, 4u);      // the consumers' LayerNorm of the later units' rows is in the L2
             a_dma(next_tile0, next_ntt);
         }
 #pragma unroll
@@ -425,20 +440,26 @@ __global__ __launch_bounds__(RS_THREADS, 2) void mlp384rs_kernel(MlpArgs p) {
             for (int s = 0; s < RS_WR - 1; ++s) wf[s] = w1[(size_t)s * 256];
         }
         for (int u = 0; u < nu; ++u) {
-            const int ntt = unit_ntt(u), it1 = (RS_HELP && u == 0) ? 12 / RS_HD / 2 : 12 / RS_HD;
+            const int ntt = unit_ntt(u), it1 = (HELP && u == 0) ? 12 / RS_HD / 2 : 12 / RS_HD;
             if (!(RS_DBG_ROLE & 1)) continue;
             if (ntt == MLP_TT && (RS_DBG_NT & 2)) {
                 produce(std::integral_constant<int, 3>{}, wave, wf, u, 0, it1, unit_tile0(u + 1), unit_ntt(u + 1), wave == 0);
-                if (RS_GSPLIT) { rs_wait(fl + 4 * RS_F_H, fh_target(u)); gelu(std::integral_constant<int, 3>{}, std::integral_constant<int, 16>{}, ntt * 16); }
+                if (RS_GSPLIT) { rs_wait(fl + 4 * RS_F_H, fh_target(u)); if (LNH == 2) rs_wait(fl + 4 * RS_F_L, 4u); gelu(std::integral_constant<int, 3>{}, std::integral_constant<int, 16>{}, ntt * 16); }
             } else if (RS_DBG_NT & 1) {
                 produce(std::integral_constant<int, 2>{}, wave, wf, u, 0, it1, unit_tile0(u + 1), unit_ntt(u + 1), wave == 0);
-                if (RS_GSPLIT) { rs_wait(fl + 4 * RS_F_H, fh_target(u)); gelu(std::integral_constant<int, 2>{}, std::integral_constant<int, 16>{}, ntt * 16); }
+                if (RS_GSPLIT) { rs_wait(fl + 4 * RS_F_H, fh_target(u)); if (LNH == 2) rs_wait(fl + 4 * RS_F_L, 4u); gelu(std::integral_constant<int, 2>{}, std::integral_constant<int, 16>{}, ntt * 16); }
             }
         }
     } else {
         // =========================================================================================== consumers
         const int j = wave - 4;
-        if (RS_HELP && (RS_DBG_ROLE & 1)) {
+        if constexpr (LNH == 2) {
+            ln_units(1, nu, j, 4);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            rs_signal(fl + 4 * RS_F_L);
+            rs_wait(fl + 4 * RS_F_L, 4u);                    // every consumer is done with the constants in the table-line slots
+        }
+        if (HELP && (RS_DBG_ROLE & 1)) {
             // the first unit's fc1, second half of the rounds: nothing else for a consumer to do until a hidden tile exists
             static_assert(!RS_HELP || 12 / RS_HD == 2, "the first unit is split by iterations");
             v4i wfh[RS_WR];
