@@ -454,6 +454,18 @@ def main():
             for _ in range(args.profile_steps):
                 eng.forward_ops(imgs)
             per = et.summary()
+        # the same operators with both LayerNorms as launches of their own (one more instrumented step): what the fused launches cost
+        # WITHOUT the LayerNorm phase inside them, so that the MFMA fraction of the GEMM work itself stays comparable across rounds
+        per_unfused = {}
+        if family == "vit" and getattr(eng, "fuse_ln_mlp", False):
+            eng.fuse_ln_mlp = eng.fuse_ln_qkv = False
+            try:
+                eng.forward_ops(imgs)
+                with EventTimer(eng.h, torch) as et2:
+                    eng.forward_ops(imgs)
+                    per_unfused = et2.summary()
+            finally:
+                eng.fuse_ln_mlp = eng.fuse_ln_qkv = True
     if rank == 0:
         ps = max(args.profile_steps, 1)
         lin_ops, bmm_ops = (vit_ops_per_image if family == "vit" else swin_ops_per_image)(cfg)
@@ -546,6 +558,14 @@ def main():
                 dominant = {"name": n, "what": ops_of[n][0], "ops_per_launch": int(ops_of[n][1]), "us_per_launch": round(us, 2),
                             "launches_per_step": per[n][1] // ps, "share_of_instrumented_step": round(per[n][0] / sum(v[0] for v in per.values()), 4),
                             "achieved": round(tops, 1), "peak": INT8_PEAK_TOPS, "unit": "TOP/s", "frac": round(tops / INT8_PEAK_TOPS, 4)}
+                # the same launch without the LayerNorm in its head (norm1 / norm2 as launches of their own, one extra instrumented step)
+                plain = {"ivit_layernorm_mlp_fused_planned": "ivit_mlp_fused_planned", "ivit_layernorm_linear_i8_qkv_planned": "ivit_linear_i8_qkv_planned"}.get(n)
+                if plain and plain in per_unfused and per_unfused[plain][1]:
+                    us0 = per_unfused[plain][0] / per_unfused[plain][1] * 1e3
+                    tops0 = ops_of[n][1] / (us0 * 1e-6) / 1e12
+                    dominant["without_layernorm_head"] = {"name": plain, "us_per_launch": round(us0, 2), "achieved": round(tops0, 1),
+                                                          "frac": round(tops0 / INT8_PEAK_TOPS, 4),
+                                                          "what": "the same GEMM work with the LayerNorm as a launch of its own (one extra instrumented step, not the timed path)"}
         roofline = {
             "kernel": "QuantLinear GEMM class: gemm_ws_qkv_kernel (D = 384: norm1 + qkv in one launch, proj + residual), gemm_as_kernel / gemm_ps_kernel / "
                       "gemm_glds_kernel (patch-embed, qkv, proj, head; fused requant epilogues) and mlp384rs_kernel / mlp384_kernel (fc1 + ShiftGELU + fc2 + "
