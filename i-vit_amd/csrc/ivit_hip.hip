@@ -28,8 +28,14 @@ struct ivit_ctx {
     int device;
     hipStream_t stream;
     int num_cu;
+    // CUs the one-workgroup-per-CU kernels (gemm_ws_qkv_kernel, mlp384rs_kernel / mlp384_kernel) size their grids for; 0 = num_cu.  The
+    // whole-model runners give the handle of a slice stream its share of the device (num_cu / slices): a slice's launch then has the
+    // per-workgroup geometry of the unsliced one (DeiT-S b256: one image per workgroup) and two slices' kernels run side by side on
+    // disjoint CUs instead of as two half-filled grids of 256 (profiles/README.md, round 6, last session)
+    int cu_share;
     char err[256];
 };
+static inline int persistent_cus(const ivit_ctx *h) { return h->cu_share > 0 ? h->cu_share : h->num_cu; }
 
 // every entry point binds the calling thread to the handle's device for the duration of the call and puts the caller's
 // current device back on the way out: one process may drive several GPUs through several handles, and a torch (or any
@@ -75,6 +81,7 @@ int ivit_create(ivit_handle *out, int device, void *hip_stream) {
     c->device = device;
     c->stream = (hipStream_t)hip_stream;
     c->err[0] = 0;
+    c->cu_share = 0;
     hipDeviceProp_t prop;
     c->num_cu = (hipGetDeviceProperties(&prop, device) == hipSuccess) ? prop.multiProcessorCount : 256;
     *out = c;
@@ -585,7 +592,7 @@ static int launch_qkv_ws(ivit_handle h, const ivit_linear_plan_s *pl, const int8
     }
     // one workgroup per CU, each with a contiguous range of 32-token tiles
     const int ntt = (a.M + 31) / 32;
-    const unsigned grid = (unsigned)(ntt < h->num_cu ? ntt : h->num_cu);
+    const unsigned grid = (unsigned)(ntt < persistent_cus(h) ? ntt : persistent_cus(h));
     const bool fma = pl->single_fma_ok;
     if (H == 0) {       // plain 8-bit output [M][N] (q = out8; T = 1)
         a.T = 1; a.H = 1;
@@ -631,7 +638,7 @@ static int launch_res_ws(ivit_handle h, const ivit_linear_plan_s *pl, const int8
         if (cached) attr_dev[h->device].store(true, std::memory_order_release);
     }
     const int ntt = (M + 31) / 32;
-    const unsigned grid = (unsigned)(ntt < h->num_cu ? ntt : h->num_cu);
+    const unsigned grid = (unsigned)(ntt < persistent_cus(h) ? ntt : persistent_cus(h));
     if (ln_out8) {
         if (pl->single_fma_ok) gemm_ws_qkv_kernel<true, true, WS_EPI_RES16><<<grid, WS_THREADS, WS_SMEM, h->stream>>>(a);
         else gemm_ws_qkv_kernel<false, true, WS_EPI_RES16><<<grid, WS_THREADS, WS_SMEM, h->stream>>>(a);
@@ -891,7 +898,7 @@ static int mlp_fused_launch(ivit_handle h, ivit_mlp_plan p, const int8_t *x, con
     // one workgroup per CU.  64-token units round-robin unless cutting contiguous tile ranges into units of <= 5 tiles
     // saves a whole round (a unit costs a pass over both weight matrices whatever its size)
     const long long ntiles = (M + 15) / 16, nunits = (ntiles + MLP_TT - 2) / (MLP_TT - 1);
-    const unsigned grid = (unsigned)(nunits < h->num_cu ? nunits : h->num_cu);
+    const unsigned grid = (unsigned)(nunits < persistent_cus(h) ? nunits : persistent_cus(h));
     const long long rounds_fixed = (nunits + grid - 1) / grid, rounds_bal = (ntiles + (long long)MLP_TT * grid - 1) / ((long long)MLP_TT * grid);
     a.balanced = rounds_bal < rounds_fixed;
     // two kernels, the same integers.  The role-split one (producer waves on fc1 of unit u + 1 beside consumer waves on

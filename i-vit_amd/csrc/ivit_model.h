@@ -86,6 +86,9 @@ SliceLayout slice_layout(const ivit_vit_s *m, int B) {
     return L;
 }
 
+#ifndef IVIT_OPT_SLICE_CU_SHARE
+#define IVIT_OPT_SLICE_CU_SHARE 1       // A/B: a slice's persistent D = 384 kernels sized for num_cu / slices (ivit_ctx::cu_share)
+#endif
 inline int slice_begin(int batch, int nslices, int i) { return (int)(((long long)batch * i) / nslices); }
 inline int max_slice(int batch, int nslices) { return (batch + nslices - 1) / nslices; }
 
@@ -329,6 +332,7 @@ int ivit_vit_forward(ivit_vit m, const int8_t *images, int batch, int nslices, v
     for (int i = 0; i < nslices; ++i) {
         const int b0 = slice_begin(batch, nslices, i), b1 = slice_begin(batch, nslices, i + 1);
         if (hipStreamWaitEvent(m->streams[i], m->fork, 0) != hipSuccess) return IVIT_ERR_HIP;
+        m->slice_h[i]->cu_share = IVIT_OPT_SLICE_CU_SHARE ? std::max(1, h->num_cu / nslices) : 0;
         rc = run_slice(m, m->slice_h[i], images + (size_t)b0 * img_bytes, b1 - b0, max_slice(batch, nslices),
                        (char *)workspace + stride * (size_t)i,
                        logits + (size_t)b0 * m->cfg.num_classes);
@@ -685,6 +689,7 @@ int ivit_swin_forward(ivit_swin m, const int8_t *images, int batch, int nslices,
     for (int i = 0; i < nslices; ++i) {
         const int b0 = slice_begin(batch, nslices, i), b1 = slice_begin(batch, nslices, i + 1);
         if (hipStreamWaitEvent(m->streams[i], m->fork, 0) != hipSuccess) return IVIT_ERR_HIP;
+        m->slice_h[i]->cu_share = IVIT_OPT_SLICE_CU_SHARE ? std::max(1, h->num_cu / nslices) : 0;
         rc = swin_run_slice(m, m->slice_h[i], images + (size_t)b0 * img_bytes, b1 - b0, (char *)workspace + stride * (size_t)i,
                             logits + (size_t)b0 * m->cfg.num_classes);
         if (rc != IVIT_OK) return rc;
