@@ -158,6 +158,7 @@ SIGNATURES = {
     "ivit_create": [ctypes.POINTER(_P), _I, _P],
     "ivit_destroy": [_P],
     "ivit_set_stream": [_P, _P],
+    "ivit_set_cu_share": [_P, ctypes.c_int],
     "ivit_quantize_input_f32": [_P, _P, _F, _P, _L],
     "ivit_normalize_quantize_u8": [_P, _P, _I, _I, _I, ctypes.POINTER(_F), ctypes.POINTER(_F), _F, _P],
     "ivit_resize_center_crop_u8": [_P, _P, _I, _I, _I, _I, _I, _P, _P],
@@ -278,6 +279,11 @@ class Handle:
 
     def set_stream(self, stream):
         self._check(self.lib.ivit_set_stream(self.h, _P(stream or 0)), "ivit_set_stream")
+
+    def set_cu_share(self, cus):
+        """CUs the one-workgroup-per-CU kernels launched through this handle size their grids for (0 = the whole device): a
+        caller running several handles side by side on slices of a batch gives each its share (include/ivit.h)."""
+        self._check(self.lib.ivit_set_cu_share(self.h, int(cus)), "ivit_set_cu_share")
 
     def _check(self, st, name):
         if st != 0:

@@ -100,6 +100,13 @@ int ivit_set_stream(ivit_handle h, void *hip_stream) {
     return IVIT_OK;
 }
 
+int ivit_set_cu_share(ivit_handle h, int cus) {
+    CHECK_H(h);
+    REQUIRE(h, cus >= 0, "cus must be >= 0 (0 = the whole device)");
+    h->cu_share = cus > h->num_cu ? h->num_cu : cus;
+    return IVIT_OK;
+}
+
 const char *ivit_last_error(ivit_handle h) { return h ? h->err : "null handle"; }
 
 // tuning / ablation switches are read once per process (thread-safe static initialisation at the call site)

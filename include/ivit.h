@@ -48,7 +48,8 @@ enum {
     IVIT_ERR_NO_DEVICE = 4
 };
 
-/* 100 * major + minor.  103 (round 6): ivit_linear_plan_prepare_ws, ivit_layernorm_linear_i8_qkv_planned,
+/* 100 * major + minor.  104 (round 6): ivit_set_cu_share (addition only).
+ * 103 (round 6): ivit_linear_plan_prepare_ws, ivit_layernorm_linear_i8_qkv_planned,
  * ivit_linear_i8_requant_residual_layernorm_planned, ivit_layernorm_linear_i8_requant_planned, ivit_patch_embed,
  * ivit_layernorm_mlp_fused_planned (additions only).
  * 102 (round 6): ivit_shiftmax_rowtable, ivit_attention_fused_rowlut (additions only).
@@ -56,7 +57,7 @@ enum {
  * fields exp_* at their END (added in 100 without a bump: a caller compiled against an older layout must be rebuilt).
  * Parameter structs are read field by field: ZERO-INITIALISE them (memset / = {0}) before filling — exp_aq == NULL (and
  * exp_nc == exp_tcount == exp_dmin == 0) selects the arithmetic Shiftmax, anything else is taken as device pointers.        */
-#define IVIT_VERSION 103
+#define IVIT_VERSION 104
 int ivit_version(void);
 const char *ivit_status_string(int status);
 
@@ -64,6 +65,12 @@ const char *ivit_status_string(int status);
 int ivit_create(ivit_handle *out, int device, void *hip_stream);
 int ivit_destroy(ivit_handle h);
 int ivit_set_stream(ivit_handle h, void *hip_stream);
+/* CUs the one-workgroup-per-CU kernels launched through `h` (the K = 384 QuantLinear layers on gemm_ws_qkv_kernel, the fused Mlp) size their
+ * grids for; 0 (the default) = every CU of the device.  A caller that runs several handles side by side on slices of a batch — what
+ * ivit_vit_forward / ivit_swin_forward do internally with nslices > 1 — gives each handle its share (CUs / slices): a slice's launch then
+ * has the per-workgroup geometry of the unsliced one and the slices' kernels run on disjoint CUs (Swin-T b256, two slices: +2.0 %).
+ * No reference counterpart (the reference has no launch geometry); results do not depend on it. */
+int ivit_set_cu_share(ivit_handle h, int cus);
 const char *ivit_last_error(ivit_handle h);
 
 /* ---- a4  QuantAct.forward, input branch  (quant_modules.py:194-196 ->

@@ -739,6 +739,15 @@ def test_layernorm_mlp_fused_equals_two_launches(M, mlp_production_case):
     H.call("ivit_layernorm_mlp_fused_planned", *args)
     assert torch.equal(got, want), int((got != want).sum())
     assert torch.equal(scratch[:M], a8) and (scratch[M] == 77).all() and len(torch.unique(want)) > 5000
+    # the same launch sized for a share of the CUs (ivit_set_cu_share: what the runners give the handle of a slice): same integers
+    for cus in (128, 100, 7):
+        H.set_cu_share(cus)
+        got.fill_(0x5555)
+        try:
+            H.call("ivit_layernorm_mlp_fused_planned", *args)
+        finally:
+            H.set_cu_share(0)
+        assert torch.equal(got, want), (cus, int((got != want).sum()))
     assert H.lib.ivit_mlp_plan_select(gm, 1) == 0            # pinned to the lock-step kernel: refused
     with pytest.raises(_lib.IvitError, match="role-split"):
         H.call("ivit_layernorm_mlp_fused_planned", *args)
@@ -1265,6 +1274,17 @@ def test_layernorm_qkv_fused_vs_oracle(H, B, T):
         assert torch.equal(alone[i], ref[i]), ("qkv on the prepared plan", "qkv"[i], int((alone[i] != ref[i]).sum()))
         assert torch.equal(fused[i], ref[i]), ("LayerNorm + qkv", "qkv"[i], int((fused[i] != ref[i]).sum()))
         assert (ref[i][-1] == 77).all() and (fused[i][-1] == 77).all()
+    # the fused launch sized for a share of the CUs (ivit_set_cu_share): more tiles per workgroup, a second panel at the large sizes — same bytes
+    for cus in (128, 33):
+        shared = mk()
+        H.set_cu_share(cus)
+        try:
+            H.call("ivit_layernorm_linear_i8_qkv_planned", prepared.p, P(xd), float(s_in), P(bi_d), P(sc_d), P(dln), P(shared[0]), P(shared[1]), P(shared[2]),
+                   B, T, Hh, dh)
+        finally:
+            H.set_cu_share(0)
+        for i in range(3):
+            assert torch.equal(shared[i], ref[i]), (cus, "qkv"[i], int((shared[i] != ref[i]).sum()))
     # a plan that was not prepared, a head dim the kernel is not built for: refused, nothing launched
     for pl, hh, dd in ((plain, Hh, dh), (prepared, 12, 32)):
         with pytest.raises(_lib.IvitError, match="prepare_ws"):
