@@ -332,7 +332,7 @@ int ivit_vit_forward(ivit_vit m, const int8_t *images, int batch, int nslices, v
     for (int i = 0; i < nslices; ++i) {
         const int b0 = slice_begin(batch, nslices, i), b1 = slice_begin(batch, nslices, i + 1);
         if (hipStreamWaitEvent(m->streams[i], m->fork, 0) != hipSuccess) return IVIT_ERR_HIP;
-        m->slice_h[i]->cu_share = IVIT_OPT_SLICE_CU_SHARE ? std::max(1, h->num_cu / nslices) : 0;
+        m->slice_h[i]->cu_share = IVIT_OPT_SLICE_CU_SHARE ? std::max(1, persistent_cus(h) / nslices) : 0;      // a share of the caller's own share
         rc = run_slice(m, m->slice_h[i], images + (size_t)b0 * img_bytes, b1 - b0, max_slice(batch, nslices),
                        (char *)workspace + stride * (size_t)i,
                        logits + (size_t)b0 * m->cfg.num_classes);
@@ -689,7 +689,7 @@ int ivit_swin_forward(ivit_swin m, const int8_t *images, int batch, int nslices,
     for (int i = 0; i < nslices; ++i) {
         const int b0 = slice_begin(batch, nslices, i), b1 = slice_begin(batch, nslices, i + 1);
         if (hipStreamWaitEvent(m->streams[i], m->fork, 0) != hipSuccess) return IVIT_ERR_HIP;
-        m->slice_h[i]->cu_share = IVIT_OPT_SLICE_CU_SHARE ? std::max(1, h->num_cu / nslices) : 0;
+        m->slice_h[i]->cu_share = IVIT_OPT_SLICE_CU_SHARE ? std::max(1, persistent_cus(h) / nslices) : 0;      // a share of the caller's own share
         rc = swin_run_slice(m, m->slice_h[i], images + (size_t)b0 * img_bytes, b1 - b0, (char *)workspace + stride * (size_t)i,
                             logits + (size_t)b0 * m->cfg.num_classes);
         if (rc != IVIT_OK) return rc;
