@@ -173,6 +173,7 @@ SIGNATURES = {
     "ivit_mlp_fused": [_P, _P, _P, _P, _P, _P, _P, _P, _P, Dyadic, Dyadic, _P, _P, _L, _I, _I],
     "ivit_patch_merge_gather": [_P, _P, _I, _I, _I, _I, _P],
     "ivit_widen_i8_i16": [_P, _P, _P, _L],
+    "ivit_linear_i8_requant8_store16": [_P, _P, _P, _P, _P, _P, _I, _I, _I],
     "ivit_patch_merge_layernorm_requant": [_P, _P, _I, _I, _I, _F, _P, _P, _P, _P],
     "ivit_swin_create": [_P, ctypes.POINTER(SwinConfigC), ctypes.POINTER(SwinParams), _I, ctypes.POINTER(_P)],
     "ivit_swin_destroy": [_P],

@@ -21,7 +21,9 @@ enum {
     EPI_RQ16_CH = 2,     // int16 = clamp16(rq(acc + bias, dy_ch[n]))
     EPI_RQ16_CH_RES = 3, // int16 = clamp16(rq(clamp16(rq(acc+bias, dy_ch[n])), main) + rq(res, resd))
     EPI_RQ8_S = 4,       // int8  = clamp8 (rq(acc, main))
-    EPI_QKV = 5          // RQ8_CH then scatter to q,k [B,H,T,dh] and vT [B,H,dh,ldv]
+    EPI_QKV = 5,         // RQ8_CH then scatter to q,k [B,H,T,dh] and vT [B,H,dh,ldv]
+    EPI_RQ8W16_CH = 6    // int16 = clamp8(rq(acc + bias, dy_ch[n])): an 8-bit QuantAct whose consumer reads the 16-bit stream
+                         // (PatchMerging's reduction, swin_quant.py:343-349, in front of the next stage's blocks); gemm_glds_kernel only
 };
 
 struct GemmArgs {

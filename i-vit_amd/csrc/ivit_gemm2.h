@@ -194,7 +194,8 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 4 : (G2_NSTAGE128 == 2 ? 4 : 3)
     __syncthreads();   // every wave done with the ring before it is reused as the staging tile
 
     constexpr bool OUT8 = (EPI == EPI_RQ8_CH || EPI == EPI_QKV);
-    constexpr int OLO = OUT8 ? -128 : -32768, OHI = OUT8 ? 127 : 32767;
+    constexpr bool CLAMP8 = OUT8 || EPI == EPI_RQ8W16_CH;          // RQ8W16: the 8-bit clamp, staged and stored as 16-bit
+    constexpr int OLO = CLAMP8 ? -128 : -32768, OHI = CLAMP8 ? 127 : 32767;
     // ---- phase 1: requant + pack 4 channels per lane -> staged tile [token][channel].
     // rne(fl64(z*c)) as loint(fl64(z*c) + 1.5*2^52): the reference's two roundings (quant_utils.py:229-231),
     // valid while |z*c| < 2^31 — checked per channel when the constants were staged; else the rint form.
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 4 : (G2_NSTAGE128 == 2 ? 4 : 3)
                 }
             }
         }
-    } else if (EPI == EPI_RQ16_CH || EPI == EPI_RQ16_CH_RES) {
+    } else if (EPI == EPI_RQ16_CH || EPI == EPI_RQ16_CH_RES || EPI == EPI_RQ8W16_CH) {
         int16_t *out = reinterpret_cast<int16_t *>(p.out);
         const double cm = p.dy_main.m * p.dy_main.r, cr = p.dy_res.m * p.dy_res.r;
         const bool res_fast = fabs(cm) < RQ_FAST_CLIM && fabs(cr) < RQ_FAST_CLIM;   // |int16 * c| < 2^24

@@ -289,6 +289,22 @@ int ivit_linear_i8_requant(ivit_handle h, const int8_t *x, const int8_t *w, cons
     return bits == 8 ? launch_gemm<false, EPI_RQ8_CH>(h, a, 1) : launch_gemm<false, EPI_RQ16_CH>(h, a, 1);
 }
 
+// QuantLinear -> QuantAct(8) whose consumer is the 16-bit stream: clamp to 8 bits, store int16 (the widening pass ivit_widen_i8_i16 folded
+// into the GEMM's stores): the Swin runner's PatchMerging reduction
+int ivit_linear_i8_requant8_store16(ivit_handle h, const int8_t *x, const int8_t *w, const int32_t *bias, const ivit_dyadic *dy_ch,
+                                    int16_t *out, int M, int N, int K) {
+    CHECK_H(h);
+    REQUIRE(h, x && w && out && dy_ch && M > 0 && N > 0 && K > 0, "bad arguments");
+    REQUIRE(h, (K % 16) == 0, "K must be a multiple of 16");
+    GemmArgs a = linear_args(x, w, bias, M, N, K);
+    a.out = out; a.dy_ch = dy_ch;
+    if (wreg_nct(a) || !use_gemm2(a)) {
+        snprintf(h->err, sizeof(h->err), "%s: built for gemm_glds_kernel's shapes (use ivit_linear_i8_requant + ivit_widen_i8_i16)", __func__);
+        return IVIT_ERR_UNSUPPORTED;
+    }
+    return launch_gemm2<EPI_RQ8W16_CH>(h, a);
+}
+
 int ivit_linear_i8_requant_residual(ivit_handle h, const int8_t *x, const int8_t *w, const int32_t *bias,
                                     const ivit_dyadic *dy_ch, ivit_dyadic dy_main, ivit_dyadic dy_res,
                                     const int16_t *residual, int16_t *out, int M, int N, int K) {

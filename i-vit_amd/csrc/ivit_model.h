@@ -412,6 +412,9 @@ struct ivit_swin_s {
 #ifndef IVIT_OPT_SWIN_WS
 #define IVIT_OPT_SWIN_WS 1             // A/B: the C = 384 stage's qkv (+ norm1) and proj layers on gemm_ws_qkv_kernel
 #endif
+#ifndef IVIT_OPT_MERGE_W16
+#define IVIT_OPT_MERGE_W16 1            // A/B: PatchMerging's reduction stores its 8-bit QuantAct as int16 (no ivit_widen_i8_i16 pass)
+#endif
 #ifndef IVIT_OPT_SWIN_LN_MLP
 #define IVIT_OPT_SWIN_LN_MLP 0
 #endif
@@ -533,8 +536,14 @@ int swin_run_slice(const ivit_swin_s *m, ivit_handle h, const int8_t *images, in
             L = res * res;
             M = (long long)B * L;
             if (!merged) RUN(swin_ln(m, h, t16, M, 4 * C, g.s_in, g.n, L, false, a8));
-            RUN(ivit_linear_i8_requant(h, a8, g.red.w, nullptr, g.red.dy, 8, ctx, (int)M, 2 * C, 4 * C));
-            RUN(ivit_widen_i8_i16(h, ctx, x, M * 2 * C));
+            // reduction -> qact2(8), stored as the 16-bit stream the next stage reads (round 6: the widening pass was 16 us per merge)
+            rc = IVIT_OPT_MERGE_W16 ? ivit_linear_i8_requant8_store16(h, a8, g.red.w, nullptr, g.red.dy, x, (int)M, 2 * C, 4 * C) : IVIT_ERR_UNSUPPORTED;
+            if (rc == IVIT_ERR_UNSUPPORTED) {
+                RUN(ivit_linear_i8_requant(h, a8, g.red.w, nullptr, g.red.dy, 8, ctx, (int)M, 2 * C, 4 * C));
+                RUN(ivit_widen_i8_i16(h, ctx, x, M * 2 * C));
+            } else {
+                RUN(rc);
+            }
         }
     }
     const int C = E << (c.num_layers - 1);

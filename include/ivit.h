@@ -48,7 +48,7 @@ enum {
     IVIT_ERR_NO_DEVICE = 4
 };
 
-/* 100 * major + minor.  104 (round 6): ivit_set_cu_share (addition only).
+/* 100 * major + minor.  104 (round 6): ivit_set_cu_share, ivit_linear_i8_requant8_store16 (additions only).
  * 103 (round 6): ivit_linear_plan_prepare_ws, ivit_layernorm_linear_i8_qkv_planned,
  * ivit_linear_i8_requant_residual_layernorm_planned, ivit_layernorm_linear_i8_requant_planned, ivit_patch_embed,
  * ivit_layernorm_mlp_fused_planned (additions only).
@@ -515,6 +515,12 @@ int ivit_patch_merge_gather(ivit_handle h, const void *x, int in_bits, int B, in
 int ivit_patch_merge_layernorm_requant(ivit_handle h, const int16_t *x, int B, int R, int C, float scale,
                                        const float *bias_int, const float *sc, const ivit_dyadic *dy_ch, int8_t *out8);
 int ivit_widen_i8_i16(ivit_handle h, const int8_t *x, int16_t *out, int64_t n);
+/* PatchMerging's reduction -> qact2 (swin_quant.py:343-349: QuantLinear(4C, 2C, bias = False) then an 8-bit QuantAct) whose consumer is the
+ * next stage's 16-bit stream: out16 = clamp8(rq(acc + bias, dy_ch[n])) stored as int16 [M][N] — ivit_linear_i8_requant(bits = 8) followed by
+ * ivit_widen_i8_i16 in one launch, same integers.  gemm_glds_kernel's shapes only (K % 32 == 0, K >= 64, not the short-K streaming kernel's):
+ * IVIT_ERR_UNSUPPORTED otherwise, nothing launched.                                                                                  */
+int ivit_linear_i8_requant8_store16(ivit_handle h, const int8_t *x, const int8_t *w, const int32_t *bias, const ivit_dyadic *dy_ch,
+                                    int16_t *out16, int M, int N, int K);
 
 /* ---- diagnostics (used by the parity tests only) ------------------------------------
  * q_ieee = n / d (compiler's correctly-rounded division) and q_lean = the hoisted-reciprocal

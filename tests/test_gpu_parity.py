@@ -305,6 +305,42 @@ def test_linear_requant_epilogues_vs_oracle(H, M, N, K):
         assert np.array_equal(out.cpu().numpy().astype(np.int32), ref), (M, N, K, s_mid)
 
 
+@pytest.mark.parametrize("M,N,K", [(1000, 192, 384), (777, 384, 768), (130, 768, 1536), (9000, 192, 384), (257, 100, 64)])
+def test_linear_requant8_store16_vs_oracle(H, M, N, K):
+    """PatchMerging's reduction -> qact2 (swin_quant.py:343-349) with the 8-bit QuantAct stored as the 16-bit stream of the next stage
+    (ivit_linear_i8_requant8_store16: the EPI_RQ8W16_CH flavour of gemm_glds_kernel) == the oracle's linear + 8-bit requant, and ==
+    ivit_linear_i8_requant(bits = 8) + ivit_widen_i8_i16; multipliers chosen so that a good share of the outputs saturate at -128 / 127;
+    no bias like the reference's layer, and with one; guard row; a short-K shape (the streaming kernel's) is refused."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(M * 3 + N + K)
+    x = rng.integers(-128, 128, (M, K), dtype=np.int8)
+    w = rng.integers(-128, 128, (N, K), dtype=np.int8)
+    xd, wd = dev(x), dev(w)
+    for with_bias in (False, True):
+        b = rng.integers(-2 ** 16, 2 ** 16, N).astype(np.int32) if with_bias else None
+        acc = orc.linear_i8(x, w, b if with_bias else np.zeros(N, np.int32))
+        s_pre = (10 ** rng.uniform(-6, -4, N)).astype(np.float32)
+        s_out = np.float32(float(np.abs(acc).std()) * float(s_pre.mean()) / 128 * 1.5)        # ~ 1.5 sigma at full scale: both rails are hit
+        d = iv.freeze.dyadic(s_pre, s_out)
+        ref = orc.requant(acc, orc.dyadic(s_pre, s_out), 8)
+        out = torch.full((M + 1, N), 0x5555, dtype=torch.int16, device="cuda")
+        bd = dev(b) if with_bias else None
+        H.call("ivit_linear_i8_requant8_store16", P(xd), P(wd), P(bd) if with_bias else None, P(dev(d)), P(out), M, N, K)
+        assert np.array_equal(out[:M].cpu().numpy().astype(np.int32), ref), (M, N, K, with_bias)
+        assert (out[M] == 0x5555).all()
+        sat = float(((ref == 127) | (ref == -128)).mean())
+        assert 0.02 < sat < 0.6 and len(np.unique(ref)) > 200, sat
+        o8 = torch.empty(M, N, dtype=torch.int8, device="cuda")
+        o16 = torch.empty(M, N, dtype=torch.int16, device="cuda")
+        H.call("ivit_linear_i8_requant", P(xd), P(wd), P(bd) if with_bias else None, P(dev(d)), 8, P(o8), M, N, K)
+        H.call("ivit_widen_i8_i16", P(o8), P(o16), M * N)
+        assert torch.equal(out[:M], o16)
+    with pytest.raises(_lib.IvitError, match="gemm_glds"):
+        big = torch.zeros(8192, 96, dtype=torch.int8, device="cuda")
+        H.call("ivit_linear_i8_requant8_store16", P(big), P(dev(rng.integers(-128, 128, (96, 96), dtype=np.int8))), None, P(dev(iv.freeze.dyadic(s_pre[:96].copy(), s_out))),
+               P(torch.empty(8192, 96, dtype=torch.int16, device="cuda")), 8192, 96, 96)
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 288, 96), (8300, 288, 96), (8200, 192, 192)])
 def test_linear_requant_saturating_multipliers(H, M, N, K):
     """multipliers far outside the magic-number range (|z c| >= 2^31 possible): every kernel of the QuantLinear family must
